@@ -1,0 +1,113 @@
+"""ctypes binding of ``libicap_hip.so`` (C ABI declared in ``include/icap_hip.h``).
+
+There is no fallback: if the library is missing or a symbol cannot be resolved the
+import of any compute path fails with a clear error, and every non-zero return
+code from the library is raised as :class:`IcapError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libicap_hip.so")
+
+ABI_VERSION = 1
+
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+
+
+class IcapError(RuntimeError):
+    pass
+
+
+class RnnWeights(C.Structure):
+    _fields_ = [
+        ("layers", C.c_int), ("H", C.c_int), ("I", C.c_int), ("V", C.c_int), ("is_lstm", C.c_int),
+        ("w_ih", C.c_void_p * 4), ("w_hh", C.c_void_p * 4), ("b_ih", C.c_void_p * 4), ("b_hh", C.c_void_p * 4),
+        ("fc_w", C.c_void_p), ("fc_b", C.c_void_p), ("in_table", C.c_void_p),
+    ]
+
+
+class TfmWeights(C.Structure):
+    _fields_ = [
+        ("E", C.c_int), ("FF", C.c_int), ("V", C.c_int),
+        ("emb", C.c_void_p),
+        ("ln2_g", C.c_void_p), ("ln2_b", C.c_void_p), ("ln3_g", C.c_void_p), ("ln3_b", C.c_void_p),
+        ("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p),
+        ("out_w", C.c_void_p), ("out_b", C.c_void_p),
+    ]
+
+
+class BahWeights(C.Structure):
+    _fields_ = [
+        ("E", C.c_int), ("H", C.c_int), ("V", C.c_int),
+        ("emb", C.c_void_p),
+        ("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p),
+        ("fc_w", C.c_void_p), ("fc_scale", C.c_void_p), ("fc_bias", C.c_void_p),
+    ]
+
+
+_p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> (restype, argtypes); must list every function include/icap_hip.h declares.
+SIGNATURES = {
+    "icap_abi_version": (_i, []),
+    "icap_last_error": (C.c_char_p, []),
+    "icap_nchw_to_nhwc_pad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "icap_conv2d_f32": (_i, [_p] * 7 + [_i] * 13 + [_p]),
+    "icap_dwconv2d_f32": (_i, [_p] * 6 + [_i] * 11 + [_p]),
+    "icap_dwconv_chunks": (_i, [_i, _i]),
+    "icap_se_gate_f32": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "icap_maxpool2d_f32": (_i, [_p, _p] + [_i] * 9 + [_p]),
+    "icap_adaptive_avgpool2d_f32": (_i, [_p, _p] + [_i] * 6 + [_p]),
+    "icap_embedding_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "icap_layernorm_f32": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _f, _f, _p]),
+    "icap_argmax_rows_f32": (_i, [_p, _i, _p, _i, _i, _i, _p, _p]),
+    "icap_mha_core_f32": (_i, [_p, _p, _p, _p] + [_i] * 6 + [_p]),
+    "icap_bahdanau_attention_f32": (_i, [_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p]),
+    "icap_lstm_pointwise_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "icap_gru_pointwise_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "icap_gemv_f32": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "icap_gemv_blocks": (_i, [_i]),
+    "icap_argmax_finalize_f32": (_i, [_p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
+    "icap_lstm_cell_f32": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "icap_gru_cell_f32": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p]),
+    "icap_greedy_rnn_f32": (_i, [C.POINTER(RnnWeights), _p, _p, _p, _p, _i, _i, _p]),
+    "icap_greedy_rnn_ws_floats": (_ll, [_i] * 5),
+    "icap_greedy_tfm_f32": (_i, [C.POINTER(TfmWeights), _p, _p, _p, _p, _p, _i, _i, _p]),
+    "icap_greedy_tfm_ws_floats": (_ll, [_i] * 4),
+    "icap_greedy_bah_f32": (_i, [C.POINTER(BahWeights), _p, _i, _p, _p, _p, _p, _i, _i, _p]),
+    "icap_greedy_bah_ws_floats": (_ll, [_i] * 5),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise IcapError when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IcapError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C image_captioning_amd/csrc`; there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover - build error
+            raise IcapError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.icap_abi_version() != ABI_VERSION:
+        raise IcapError(f"ABI mismatch: library {lib.icap_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().icap_last_error().decode("utf-8", "replace")
+        raise IcapError(f"{what or 'icap'} failed (code {rc}): {msg}")

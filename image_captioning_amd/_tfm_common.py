@@ -1,0 +1,249 @@
+"""Shared implementation of the word-level and char-level transformer captioners.
+
+Both reference files (transformer_word_level.py:28-112, transformercharmiguel.py:30-113)
+define the same three classes and differ only in where the vocabulary size comes
+from and in head counts.  The classes here hold the parameters under the
+reference's names and run their eval-mode forward through ``libicap_hip.so``.
+
+Semantics that the kernels reproduce on purpose (they are what the reference
+computes, even where they look accidental):
+
+* the encoder block feeds ``[B, 1, E]`` to a sequence-first ``nn.MultiheadAttention``,
+  so the B images of a batch attend to each other (sequence length B, batch 1);
+* the decoder block tiles the B encoder rows and gives them to every batch column
+  as keys: each caption position attends over all B images (tiling a key T times
+  does not change a softmax-weighted sum, so the kernels use the B unique rows);
+* the decoder has no self-attention in use, no causal mask and no positional
+  encoding: logits at position t depend on token t and the batch's images only.
+  ``attention`` / ``layer_norm1`` of the decoder are parameters that never run.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.nn import Dropout
+
+from . import ops
+from .backbones import PreparedCache, require_eval
+
+MAX_LOCKSTEP = 8
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+def _mha_weights(mha: nn.MultiheadAttention):
+    E = mha.embed_dim
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    return {
+        "heads": mha.num_heads,
+        "wq": _f32(w[:E]), "wk": _f32(w[E:2 * E]), "wv": _f32(w[2 * E:]),
+        "bq": _f32(b[:E]), "bk": _f32(b[E:2 * E]), "bv": _f32(b[2 * E:]),
+        "wo": _f32(mha.out_proj.weight), "bo": _f32(mha.out_proj.bias),
+    }
+
+
+class TransformerEncoderBlockBase(nn.Module):
+    def __init__(self, embed_dim, dense_dim, num_heads, dropout=0.3):
+        super().__init__()
+        self.attention = nn.MultiheadAttention(embed_dim, num_heads)
+        self.layer_norm1 = nn.LayerNorm(embed_dim)
+        self.layer_norm2 = nn.LayerNorm(embed_dim)
+        self.fc = nn.Sequential(nn.Linear(embed_dim, dense_dim), nn.ReLU(), Dropout(dropout),
+                                nn.Linear(dense_dim, embed_dim), Dropout(dropout))
+        self.dropout = Dropout(dropout)
+        self._prep = PreparedCache()
+
+    def _build(self):
+        return {"att": _mha_weights(self.attention),
+                "ln1": (_f32(self.layer_norm1.weight), _f32(self.layer_norm1.bias)),
+                "ln2": (_f32(self.layer_norm2.weight), _f32(self.layer_norm2.bias)),
+                "fc0": (_f32(self.fc[0].weight), _f32(self.fc[0].bias)),
+                "fc3": (_f32(self.fc[3].weight), _f32(self.fc[3].bias))}
+
+    def _ffn_tail(self, p, x, attn):
+        x1 = ops.layernorm(attn, *p["ln1"], res=x)
+        h = ops.linear(x1, *p["fc0"], act=ops.ACT_RELU)
+        f = ops.linear(h, *p["fc3"])
+        return ops.layernorm(f, *p["ln2"], res=x1)
+
+    def forward(self, x):
+        """x [1, B, E] -> [B, 1, E]; self-attention runs ACROSS the B images (transformer_word_level.py:43-49)."""
+        require_eval(self, "TransformerEncoderBlock")
+        p = self._prep.get(self, self._build)
+        a = p["att"]
+        one, B, E = x.shape
+        if one != 1:
+            raise ValueError("TransformerEncoderBlock expects the image embedding as [1, B, E]")
+        rows = x.reshape(B, E).float().contiguous()
+        q = ops.linear(rows, a["wq"], a["bq"])
+        k = ops.linear(rows, a["wk"], a["bk"])
+        v = ops.linear(rows, a["wv"], a["bv"])
+        att = ops.mha_core(q.view(B, 1, E), k.view(B, 1, E), v.view(B, 1, E), a["heads"]).view(B, E)
+        att = ops.linear(att, a["wo"], a["bo"])
+        return self._ffn_tail(p, rows, att).view(B, 1, E)
+
+    def forward_independent(self, rows):
+        """Each row as its own batch of one (what generate_caption computes image by image): with a single
+        key the attention output is out_proj(W_v x + b_v).  rows [B, E] -> [B, E]."""
+        require_eval(self, "TransformerEncoderBlock")
+        p = self._prep.get(self, self._build)
+        a = p["att"]
+        rows = rows.float().contiguous()
+        att = ops.linear(ops.linear(rows, a["wv"], a["bv"]), a["wo"], a["bo"])
+        return self._ffn_tail(p, rows, att)
+
+
+class TransformerDecoderBlockBase(nn.Module):
+    def __init__(self, embed_dim, ff_dim, num_heads, vocab_size, dropout=0.3):
+        super().__init__()
+        self.attention = nn.MultiheadAttention(embed_dim, num_heads)        # never used by forward (as in the reference)
+        self.cross_attention = nn.MultiheadAttention(embed_dim, num_heads)
+        self.layer_norm1 = nn.LayerNorm(embed_dim)                           # never used by forward
+        self.layer_norm2 = nn.LayerNorm(embed_dim)
+        self.layer_norm3 = nn.LayerNorm(embed_dim)
+        self.fc = nn.Sequential(nn.Linear(embed_dim, ff_dim), nn.ReLU(), Dropout(dropout),
+                                nn.Linear(ff_dim, embed_dim), Dropout(dropout))
+        self.output_fc = nn.Linear(embed_dim, vocab_size)
+        self.dropout = Dropout(dropout)
+        self._prep = PreparedCache()
+
+    def _build(self):
+        return {"att": _mha_weights(self.cross_attention),
+                "ln2": (_f32(self.layer_norm2.weight), _f32(self.layer_norm2.bias)),
+                "ln3": (_f32(self.layer_norm3.weight), _f32(self.layer_norm3.bias)),
+                "fc0": (_f32(self.fc[0].weight), _f32(self.fc[0].bias)),
+                "fc3": (_f32(self.fc[3].weight), _f32(self.fc[3].bias)),
+                "out": (_f32(self.output_fc.weight), _f32(self.output_fc.bias))}
+
+    def _rows_forward(self, p, x_rows, enc_rows):
+        """x_rows [R, E] caption embeddings (any row order), enc_rows [B, E] -> logits [R, V]."""
+        a = p["att"]
+        R, E = x_rows.shape
+        Bk = enc_rows.shape[0]
+        q = ops.linear(x_rows, a["wq"], a["bq"])
+        k = ops.linear(enc_rows, a["wk"], a["bk"])
+        v = ops.linear(enc_rows, a["wv"], a["bv"])
+        ca = ops.mha_core(q.view(R, 1, E), k.view(Bk, 1, E), v.view(Bk, 1, E), a["heads"]).view(R, E)
+        ca = ops.linear(ca, a["wo"], a["bo"])
+        x = ops.layernorm(ca, *p["ln2"], res=x_rows)
+        h = ops.linear(x, *p["fc0"], act=ops.ACT_RELU)
+        f = ops.linear(h, *p["fc3"])
+        x = ops.layernorm(f, *p["ln3"], res=x)
+        return ops.linear(x, *p["out"])
+
+    def forward(self, x, encoder_out):
+        """x [T, B, E], encoder_out [B, 1, E] -> logits [T, B, V]  (transformer_word_level.py:72-79)."""
+        require_eval(self, "TransformerDecoderBlock")
+        p = self._prep.get(self, self._build)
+        T, B, E = x.shape
+        logits = self._rows_forward(p, x.reshape(T * B, E).float().contiguous(),
+                                    encoder_out.reshape(-1, E).float().contiguous())
+        return logits.view(T, B, -1)
+
+    def cross_attention_single(self, enc_rows):
+        """Cross-attention output when the batch holds one image: out_proj(W_v enc + b_v), [B, E]."""
+        p = self._prep.get(self, self._build)
+        a = p["att"]
+        return ops.linear(ops.linear(enc_rows.float().contiguous(), a["wv"], a["bv"]), a["wo"], a["bo"])
+
+
+class ImageCaptioningModelBase(nn.Module):
+    start_token = 2
+    end_token = 3
+
+    def __init__(self, cnn_model, encoder, decoder, vocab_size, num_captions_per_image=5, embed_dim=512):
+        super().__init__()
+        self.cnn_model = cnn_model
+        self.encoder = encoder
+        self.decoder = decoder
+        self.num_captions_per_image = num_captions_per_image
+        self.caption_embedding = nn.Embedding(vocab_size, embed_dim)
+        self._prep = PreparedCache()
+
+    def forward(self, images, captions):
+        """images [B,3,H,W], captions [B,T] int64 -> logits [B,T,V]  (transformer_word_level.py:92-112)."""
+        require_eval(self, "ImageCaptioningModel")
+        img_embed = self.cnn_model(images)                                  # [B, E]
+        return self.forward_features(img_embed, captions)
+
+    def forward_features(self, img_embed, captions):
+        """Same as forward but from the CNN output [B, E]."""
+        require_eval(self, "ImageCaptioningModel")
+        B, T = captions.shape
+        E = img_embed.shape[-1]
+        enc = self.encoder(img_embed.view(1, B, E))                         # [B, 1, E], coupled across the batch
+        emb, err = ops.embedding(_f32(self.caption_embedding.weight), captions.contiguous().view(-1))  # rows (b, t)
+        p = self.decoder._prep.get(self.decoder, self.decoder._build)
+        logits = self.decoder._rows_forward(p, emb, enc.view(B, E))
+        return logits.view(B, T, -1)
+
+    # -- greedy captioning ---------------------------------------------------------------------
+    def _greedy_weights(self):
+        def build():
+            p = self.decoder._build()
+            return {"emb": _f32(self.caption_embedding.weight),
+                    "ln2_g": p["ln2"][0], "ln2_b": p["ln2"][1], "ln3_g": p["ln3"][0], "ln3_b": p["ln3"][1],
+                    "fc1_w": p["fc0"][0], "fc1_b": p["fc0"][1], "fc2_w": p["fc3"][0], "fc2_b": p["fc3"][1],
+                    "out_w": p["out"][0], "out_b": p["out"][1]}
+        return self._prep.get(self, build)
+
+    def greedy_ids_from_features(self, img_embed, max_len, want_logits=False, lockstep=None):
+        """Greedy decoding of every image as its own batch of one (the semantics of generate_caption,
+        TransformerTest.py:126-164, with argmax in place of top-k sampling).  The CNN / encoder / cross-attention
+        results do not depend on the step, so they are computed once.  Returns ids [B, max_len] on the device."""
+        require_eval(self, "ImageCaptioningModel")
+        wd = self._greedy_weights()
+        enc = self.encoder.forward_independent(img_embed)
+        ca = self.decoder.cross_attention_single(enc)                        # [B, E]
+        B = ca.shape[0]
+        start = torch.full((B,), self.start_token, device=ca.device, dtype=torch.int64)
+        lock = MAX_LOCKSTEP if lockstep is None else lockstep
+        if B <= lock:
+            return self._greedy_small(wd, ca, start, max_len, want_logits)
+        return self._greedy_gemm(wd, ca, start, max_len, want_logits)
+
+    def _greedy_small(self, wd, ca, start, max_len, want_logits):
+        ids, logits = [], []
+        for s in range(0, ca.shape[0], MAX_LOCKSTEP):
+            i, lg = ops.greedy_tfm(wd, ca[s:s + MAX_LOCKSTEP].contiguous(), start[s:s + MAX_LOCKSTEP].contiguous(),
+                                   max_len, want_logits)
+            ids.append(i)
+            logits.append(lg)
+        ids = torch.cat(ids, 0)
+        return (ids, torch.cat(logits, 1)) if want_logits else ids
+
+    def _greedy_gemm(self, wd, ca, start, max_len, want_logits):
+        """Large image batches: each step is a handful of [B, *] GEMMs on the matrix cores."""
+        B = ca.shape[0]
+        ids = torch.empty((B, max_len), device=ca.device, dtype=torch.int64)
+        tok = start
+        all_logits = []
+        for t in range(max_len):
+            xin, _ = ops.embedding(wd["emb"], tok, add=ca)
+            x = ops.layernorm(xin, wd["ln2_g"], wd["ln2_b"])
+            h = ops.linear(x, wd["fc1_w"], wd["fc1_b"], act=ops.ACT_RELU)
+            f = ops.linear(h, wd["fc2_w"], wd["fc2_b"])
+            x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"], res=x)
+            logits = ops.linear(x2, wd["out_w"], wd["out_b"])
+            tok = ops.argmax_rows(logits)
+            ids[:, t].copy_(tok)
+            if want_logits:
+                all_logits.append(logits)
+        return (ids, torch.stack(all_logits, 0)) if want_logits else ids
+
+    def caption_ids(self, images, max_len=10):
+        """Greedy captions (lists of ids, start token dropped, cut before the end token)."""
+        feats = self.cnn_model(images)
+        ids = self.greedy_ids_from_features(feats, max_len).tolist()
+        return [cut_before_end(r, self.end_token) for r in ids]
+
+
+def cut_before_end(row, end_token):
+    out = []
+    for t in row:
+        if t == end_token:
+            break
+        out.append(int(t))
+    return out

@@ -1,0 +1,290 @@
+// extern "C" surface of libicap_hip.so (declared in include/icap_hip.h) and the
+// greedy decode drivers, which enqueue a whole caption's worth of step kernels on
+// the caller's stream without touching the host in between.
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.hpp"
+#include "../../include/icap_hip.h"
+
+namespace icap {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// kernels implemented in the other translation units
+int conv_igemm_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int,
+                   int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int nchw_to_nhwc_pad_f32(const float*, float*, int, int, int, int, int, hipStream_t);
+int dwconv2d_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
+                 int, int, int, int, int, hipStream_t);
+int dwconv_chunks(int, int, int*);
+int se_gate_f32(const float*, int, float, const float*, const float*, const float*, const float*, float*, int, int, int,
+                hipStream_t);
+int maxpool2d_f32(const float*, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int adaptive_avgpool2d_f32(const float*, float*, int, int, int, int, int, int, hipStream_t);
+int embedding_f32(const float*, const long long*, const float*, float*, int, int, int, int, int*, hipStream_t);
+int layernorm_f32(const float*, const float*, int, const float*, const float*, float*, int, int, float, float, hipStream_t);
+int argmax_rows_f32(const float*, int, long long*, int, int, int, float*, hipStream_t);
+int mha_core_f32(const float*, const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
+int bahdanau_attention_f32(const float*, const float*, const float*, float, const float*, float*, float*, int, int, int,
+                           hipStream_t);
+int lstm_pointwise_f32(const float*, const float*, float*, float*, int, int, hipStream_t);
+int gru_pointwise_f32(const float*, const float*, const float*, float*, int, int, hipStream_t);
+int gemv_f32(const float*, const float*, const float*, const float*, int, float*, int, int, int, int, int, float*, int*,
+             hipStream_t);
+int gemv_blocks(int);
+int argmax_finalize_f32(const float*, const int*, int, long long*, int, const float*, const float*, float*, int, int, int,
+                        hipStream_t);
+int lstm_cell_f32(const float*, const float*, const float*, const float*, const float*, int, const float*, const float*,
+                  float*, float*, int, int, int, hipStream_t);
+int gru_cell_f32(const float*, const float*, const float*, const float*, const float*, int, const float*, float*, int, int,
+                 int, hipStream_t);
+
+static inline long long align4(long long n) { return (n + 3) & ~3LL; }
+
+#define ICAP_TRY(expr)            \
+    do {                          \
+        const int rc_ = (expr);   \
+        if (rc_ != ICAP_OK) return rc_; \
+    } while (0)
+
+}  // namespace icap
+
+using namespace icap;
+
+extern "C" {
+
+int icap_abi_version(void) { return ICAP_ABI_VERSION; }
+const char* icap_last_error(void) { return g_err; }
+
+int icap_nchw_to_nhwc_pad_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream) {
+    return nchw_to_nhwc_pad_f32(src, dst, B, C, H, W, Cp, (hipStream_t)stream);
+}
+
+int icap_conv2d_f32(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                    const float* gate, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                    int pad_t, int pad_l, int Ho, int Wo, int act, void* stream) {
+    return conv_igemm_f32(x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo,
+                          act, (hipStream_t)stream);
+}
+
+int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y, float* partial,
+                      int B, int H, int W, int C, int KS, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                      void* stream) {
+    return dwconv2d_f32(x, w, scale, bias, y, partial, B, H, W, C, KS, stride, pad_t, pad_l, Ho, Wo, act, (hipStream_t)stream);
+}
+
+int icap_dwconv_chunks(int Ho, int Wo) { return dwconv_chunks(Ho, Wo, nullptr); }
+
+int icap_se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr, const float* br, const float* we,
+                     const float* be, float* gate, int B, int C, int S, void* stream) {
+    return se_gate_f32(partial, nchunks, inv_hw, wr, br, we, be, gate, B, C, S, (hipStream_t)stream);
+}
+
+int icap_maxpool2d_f32(const float* x, float* y, int B, int H, int W, int C, int KS, int stride, int pad, int Ho, int Wo,
+                       void* stream) {
+    return maxpool2d_f32(x, y, B, H, W, C, KS, stride, pad, Ho, Wo, (hipStream_t)stream);
+}
+
+int icap_adaptive_avgpool2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, void* stream) {
+    return adaptive_avgpool2d_f32(x, y, B, H, W, C, OH, OW, (hipStream_t)stream);
+}
+
+int icap_embedding_f32(const float* table, const long long* idx, const float* add, float* out, int rows, int E, int V,
+                       int* err_flag, void* stream) {
+    return embedding_f32(table, idx, add, out, E, rows, E, V, err_flag, (hipStream_t)stream);
+}
+
+int icap_layernorm_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta, float* y,
+                       int rows, int E, float eps, float pre_scale, void* stream) {
+    return layernorm_f32(x, res, res_rows, gamma, beta, y, rows, E, eps, pre_scale, (hipStream_t)stream);
+}
+
+int icap_argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_stride, int rows, int V, float* top2gap,
+                         void* stream) {
+    return argmax_rows_f32(logits, ld, idx, idx_stride, rows, V, top2gap, (hipStream_t)stream);
+}
+
+int icap_mha_core_f32(const float* q, const float* k, const float* v, float* out, int Lq, int Lk, int N, int Nk, int E,
+                      int heads, void* stream) {
+    return mha_core_f32(q, k, v, out, Lq, Lk, N, Nk, E, heads, (hipStream_t)stream);
+}
+
+int icap_bahdanau_attention_f32(const float* u, const float* w, const float* a_w, float a_b, const float* feat,
+                                float* alpha, float* context, int B, int A, int E, void* stream) {
+    return bahdanau_attention_f32(u, w, a_w, a_b, feat, alpha, context, B, A, E, (hipStream_t)stream);
+}
+
+int icap_lstm_pointwise_f32(const float* gates, const float* c_in, float* h_out, float* c_out, int B, int H, void* stream) {
+    return lstm_pointwise_f32(gates, c_in, h_out, c_out, B, H, (hipStream_t)stream);
+}
+
+int icap_gru_pointwise_f32(const float* gi, const float* gh, const float* h_in, float* h_out, int B, int H, void* stream) {
+    return gru_pointwise_f32(gi, gh, h_in, h_out, B, H, (hipStream_t)stream);
+}
+
+int icap_gemv_f32(const float* W, const float* scale, const float* bias, const float* x, int ldx, float* y, int ldy,
+                  int NB, int N, int K, int act, float* part_val, int* part_idx, void* stream) {
+    return gemv_f32(W, scale, bias, x, ldx, y, ldy, NB, N, K, act, part_val, part_idx, (hipStream_t)stream);
+}
+
+int icap_gemv_blocks(int N) { return gemv_blocks(N); }
+
+int icap_argmax_finalize_f32(const float* part_val, const int* part_idx, int nparts, long long* ids, int ids_stride,
+                             const float* table, const float* add, float* next_x, int ldx, int E, int NB, void* stream) {
+    return argmax_finalize_f32(part_val, part_idx, nparts, ids, ids_stride, table, add, next_x, ldx, E, NB, (hipStream_t)stream);
+}
+
+int icap_lstm_cell_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* x, int ldx,
+                       const float* h_in, const float* c_in, float* h_out, float* c_out, int NB, int I, int H, void* stream) {
+    return lstm_cell_f32(w_ih, w_hh, b_ih, b_hh, x, ldx, h_in, c_in, h_out, c_out, NB, I, H, (hipStream_t)stream);
+}
+
+int icap_gru_cell_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* x, int ldx,
+                      const float* h_in, float* h_out, int NB, int I, int H, void* stream) {
+    return gru_cell_f32(w_ih, w_hh, b_ih, b_hh, x, ldx, h_in, h_out, NB, I, H, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ greedy: seq2seq LSTM / GRU
+// workspace (floats): x [NB][I] | h [2][layers][NB][H] | c [2][layers][NB][H] | part_val [NB][P] | part_idx [NB][P]
+long long icap_greedy_rnn_ws_floats(int NB, int layers, int H, int I, int V) {
+    const long long P = gemv_blocks(V);
+    return align4((long long)NB * I) + 4LL * layers * align4((long long)NB * H) + 2 * align4((long long)NB * P);
+}
+
+int icap_greedy_rnn_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, float* ws, int NB,
+                        int steps, void* stream) {
+    if (!w || !x0 || !ids || !ws || NB <= 0 || steps <= 0) { set_error("greedy_rnn: bad arguments"); return ICAP_ERR_ARG; }
+    if (w->layers <= 0 || w->layers > 4 || w->H <= 0 || w->I <= 0 || w->V <= 0 || !w->fc_w || !w->fc_b || !w->in_table) {
+        set_error("greedy_rnn: bad weight descriptor");
+        return ICAP_ERR_ARG;
+    }
+    if (NB > 8) { set_error("greedy_rnn: NB=%d exceeds 8 captions per call", NB); return ICAP_ERR_LIMIT; }
+    hipStream_t st = (hipStream_t)stream;
+    const int L = w->layers, H = w->H, I = w->I, V = w->V;
+    const int P = gemv_blocks(V);
+    const long long hsz = align4((long long)NB * H);
+    float* x = ws;
+    float* hbuf = x + align4((long long)NB * I);
+    float* cbuf = hbuf + 2LL * L * hsz;
+    float* pv = cbuf + 2LL * L * hsz;
+    int* pi = reinterpret_cast<int*>(pv + align4((long long)NB * P));
+    // hidden=None in the reference means zero state (seq2seqbasic.py:74)
+    hipError_t e = hipMemsetAsync(hbuf, 0, sizeof(float) * 4LL * L * hsz, st);
+    if (e != hipSuccess) { set_error("greedy_rnn: memset: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
+    e = hipMemcpyAsync(x, x0, sizeof(float) * (size_t)NB * I, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { set_error("greedy_rnn: copy: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
+    int cur = 0;
+    for (int t = 0; t < steps; ++t) {
+        const float* in = x;
+        int in_ld = I, in_w = I;
+        for (int l = 0; l < L; ++l) {
+            const float* h_in = hbuf + (2LL * l + cur) * hsz;
+            float* h_out = hbuf + (2LL * l + (cur ^ 1)) * hsz;
+            const float* c_in = cbuf + (2LL * l + cur) * hsz;
+            float* c_out = cbuf + (2LL * l + (cur ^ 1)) * hsz;
+            if (w->is_lstm)
+                ICAP_TRY(lstm_cell_f32(w->w_ih[l], w->w_hh[l], w->b_ih[l], w->b_hh[l], in, in_ld, h_in, c_in, h_out, c_out, NB, in_w, H, st));
+            else
+                ICAP_TRY(gru_cell_f32(w->w_ih[l], w->w_hh[l], w->b_ih[l], w->b_hh[l], in, in_ld, h_in, h_out, NB, in_w, H, st));
+            in = h_out; in_ld = H; in_w = H;
+        }
+        float* lo = logits_out ? logits_out + (size_t)t * NB * V : nullptr;
+        ICAP_TRY(gemv_f32(w->fc_w, nullptr, w->fc_b, in, H, lo, V, NB, V, H, ACT_NONE, pv, pi, st));
+        ICAP_TRY(argmax_finalize_f32(pv, pi, P, ids + t, steps, w->in_table, nullptr, x, I, I, NB, st));
+        cur ^= 1;
+    }
+    return ICAP_OK;
+}
+
+// ------------------------------------------------------------------ greedy: word / char transformer
+// workspace: xin [NB][E] | x [NB][E] | h [NB][FF] | y [NB][E] | x2 [NB][E] | part_val | part_idx
+long long icap_greedy_tfm_ws_floats(int NB, int E, int FF, int V) {
+    const long long P = gemv_blocks(V);
+    return 4 * align4((long long)NB * E) + align4((long long)NB * FF) + 2 * align4((long long)NB * P);
+}
+
+int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
+                        float* logits_out, float* ws, int NB, int steps, void* stream) {
+    if (!w || !ca || !start_ids || !ids || !ws || NB <= 0 || steps <= 0) { set_error("greedy_tfm: bad arguments"); return ICAP_ERR_ARG; }
+    if (w->E <= 0 || w->FF <= 0 || w->V <= 0 || !w->emb || !w->ln2_g || !w->ln2_b || !w->ln3_g || !w->ln3_b || !w->fc1_w ||
+        !w->fc1_b || !w->fc2_w || !w->fc2_b || !w->out_w || !w->out_b) {
+        set_error("greedy_tfm: bad weight descriptor");
+        return ICAP_ERR_ARG;
+    }
+    if (NB > 8) { set_error("greedy_tfm: NB=%d exceeds 8 captions per call", NB); return ICAP_ERR_LIMIT; }
+    hipStream_t st = (hipStream_t)stream;
+    const int E = w->E, FF = w->FF, V = w->V, P = gemv_blocks(V);
+    const long long esz = align4((long long)NB * E);
+    float* xin = ws;
+    float* x = xin + esz;
+    float* y = x + esz;
+    float* x2 = y + esz;
+    float* h = x2 + esz;
+    float* pv = h + align4((long long)NB * FF);
+    int* pi = reinterpret_cast<int*>(pv + align4((long long)NB * P));
+    ICAP_TRY(embedding_f32(w->emb, start_ids, ca, xin, E, NB, E, V, nullptr, st));
+    for (int t = 0; t < steps; ++t) {
+        ICAP_TRY(layernorm_f32(xin, nullptr, 1, w->ln2_g, w->ln2_b, x, NB, E, 1e-5f, 1.f, st));
+        ICAP_TRY(gemv_f32(w->fc1_w, nullptr, w->fc1_b, x, E, h, FF, NB, FF, E, ACT_RELU, nullptr, nullptr, st));
+        ICAP_TRY(gemv_f32(w->fc2_w, nullptr, w->fc2_b, h, FF, y, E, NB, E, FF, ACT_NONE, nullptr, nullptr, st));
+        ICAP_TRY(layernorm_f32(y, x, NB, w->ln3_g, w->ln3_b, x2, NB, E, 1e-5f, 1.f, st));
+        float* lo = logits_out ? logits_out + (size_t)t * NB * V : nullptr;
+        ICAP_TRY(gemv_f32(w->out_w, nullptr, w->out_b, x2, E, lo, V, NB, V, E, ACT_NONE, pv, pi, st));
+        ICAP_TRY(argmax_finalize_f32(pv, pi, P, ids + t, steps, w->emb, ca, xin, E, E, NB, st));
+    }
+    return ICAP_OK;
+}
+
+// ------------------------------------------------------------------ greedy: Bahdanau LSTMCell decoder
+// workspace: x [NB][E+ENC] | h [2][NB][H] | c [2][NB][H] | part_val | part_idx
+long long icap_greedy_bah_ws_floats(int NB, int E, int ENC, int H, int V) {
+    const long long P = gemv_blocks(V);
+    return align4((long long)NB * (E + ENC)) + 4 * align4((long long)NB * H) + 2 * align4((long long)NB * P);
+}
+
+int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
+                        long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream) {
+    if (!w || !context || !start_ids || !ids || !ws || NB <= 0 || steps <= 0 || ENC <= 0) { set_error("greedy_bah: bad arguments"); return ICAP_ERR_ARG; }
+    if (w->E <= 0 || w->H <= 0 || w->V <= 0 || !w->emb || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh || !w->fc_w) {
+        set_error("greedy_bah: bad weight descriptor");
+        return ICAP_ERR_ARG;
+    }
+    if (NB > 8) { set_error("greedy_bah: NB=%d exceeds 8 captions per call", NB); return ICAP_ERR_LIMIT; }
+    if ((w->E % 4) || (ENC % 4)) { set_error("greedy_bah: E and ENC must be multiples of 4"); return ICAP_ERR_ALIGN; }
+    hipStream_t st = (hipStream_t)stream;
+    const int E = w->E, H = w->H, V = w->V, I = E + ENC, P = gemv_blocks(V);
+    const long long hsz = align4((long long)NB * H);
+    float* x = ws;
+    float* hbuf = x + align4((long long)NB * I);
+    float* cbuf = hbuf + 2 * hsz;
+    float* pv = cbuf + 2 * hsz;
+    int* pi = reinterpret_cast<int*>(pv + align4((long long)NB * P));
+    hipError_t e = hipMemsetAsync(hbuf, 0, sizeof(float) * 4 * hsz, st);  // init_hidden_state: zeros
+    if (e != hipSuccess) { set_error("greedy_bah: memset: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
+    // x[b] = [ emb[start] | context[b] ]; the context half never changes
+    e = hipMemcpy2DAsync(x + E, sizeof(float) * I, context, sizeof(float) * ENC, sizeof(float) * ENC, NB, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { set_error("greedy_bah: copy: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
+    ICAP_TRY(embedding_f32(w->emb, start_ids, nullptr, x, I, NB, E, V, nullptr, st));
+    int cur = 0;
+    for (int t = 0; t < steps; ++t) {
+        const float* h_in = hbuf + cur * hsz;
+        float* h_out = hbuf + (cur ^ 1) * hsz;
+        const float* c_in = cbuf + cur * hsz;
+        float* c_out = cbuf + (cur ^ 1) * hsz;
+        ICAP_TRY(lstm_cell_f32(w->w_ih, w->w_hh, w->b_ih, w->b_hh, x, I, h_in, c_in, h_out, c_out, NB, I, H, st));
+        float* lo = logits_out ? logits_out + (size_t)t * NB * V : nullptr;
+        ICAP_TRY(gemv_f32(w->fc_w, w->fc_scale, w->fc_bias, h_out, H, lo, V, NB, V, H, ACT_NONE, pv, pi, st));
+        ICAP_TRY(argmax_finalize_f32(pv, pi, P, ids + t, steps, w->emb, nullptr, x, I, E, NB, st));
+        cur ^= 1;
+    }
+    return ICAP_OK;
+}
+
+}  // extern "C"

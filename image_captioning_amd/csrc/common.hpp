@@ -1,0 +1,81 @@
+// Shared device helpers for the gfx950 captioning kernels.
+// Everything here is wave64 / CDNA4 specific; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icap {
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
+
+// Error codes returned across the C ABI (0 = ok). Values >= 1000 are
+// 1000 + hipError_t of a failed launch.
+enum Err : int {
+    ICAP_OK = 0,
+    ICAP_ERR_ARG = 1,        // null pointer / non-positive size / unsupported shape
+    ICAP_ERR_ALIGN = 2,      // pointer or channel count not aligned as the kernel needs
+    ICAP_ERR_LIMIT = 3,      // a size exceeds a compiled-in maximum
+    ICAP_ERR_HIP_BASE = 1000
+};
+
+void set_error(const char* fmt, ...);
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return ICAP_ERR_HIP_BASE + (int)e;
+    }
+    return ICAP_OK;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_SWISH: return v * sigmoidf_(v);
+        case ACT_SIGMOID: return sigmoidf_(v);
+        case ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// 64-lane butterfly sum: every lane ends with the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// (value, index) max with first-index tie-break, the order torch.argmax uses.
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(v, o, 64);
+        int oi = __shfl_xor(i, o, 64);
+        argmax_combine(v, i, ov, oi);
+    }
+}
+
+__device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+    return acc;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace icap

@@ -1,0 +1,307 @@
+// Row-wise kernels of the caption decoders (fp32): embedding gather, LayerNorm
+// with fused residual, arg-max over the vocabulary, multi-head attention over a
+// short key list, Bahdanau additive attention, and the LSTM / GRU gate
+// non-linearities that follow a batched gate GEMM.  One wave owns one row (or one
+// query/head pair); reductions are 64-lane butterflies, never atomics, so results
+// are reproducible run to run.
+#include "common.hpp"
+
+namespace icap {
+
+// ---------------------------------------------------------------- embedding
+// out[r][:] = table[idx[r]][:] (+ add[r][:] when given)
+__global__ void embedding_kernel(const float* __restrict__ table, const long long* __restrict__ idx,
+                                 const float* __restrict__ add, float* __restrict__ out, int ldo, int rows,
+                                 int E, int V, int* __restrict__ err) {
+    const int r = blockIdx.x;
+    long long t = idx[r];
+    if (t < 0 || t >= V) { if (threadIdx.x == 0 && err) *err = 1; t = 0; }
+    const float* src = table + (size_t)t * E;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        float v = src[e];
+        if (add) v += add[(size_t)r * E + e];
+        out[(size_t)r * ldo + e] = v;
+    }
+}
+
+int embedding_f32(const float* table, const long long* idx, const float* add, float* out, int ldo, int rows, int E,
+                  int V, int* err_flag, hipStream_t st) {
+    if (!table || !idx || !out || rows <= 0 || E <= 0 || V <= 0 || ldo < E) { set_error("embedding: bad arguments"); return ICAP_ERR_ARG; }
+    hipLaunchKernelGGL(embedding_kernel, dim3(rows), dim3(128), 0, st, table, idx, add, out, ldo, rows, E, V, err_flag);
+    return launch_status("embedding");
+}
+
+// ---------------------------------------------------------------- LayerNorm
+// y[r] = LN(x[r] + res[r % res_rows]) * gamma + beta ; one wave per row.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        int res_rows, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        int rows, int E, float eps, float pre_scale) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * E;
+    const float* rr = res ? res + (size_t)(r % res_rows) * E : nullptr;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        float v = xr[e] * pre_scale;
+        if (rr) v += rr[e];
+        s += v;
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        float v = xr[e] * pre_scale;
+        if (rr) v += rr[e];
+        const float d = v - mean;
+        q = fmaf(d, d, q);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
+    for (int e = lane; e < E; e += 64) {
+        float v = xr[e] * pre_scale;
+        if (rr) v += rr[e];
+        y[(size_t)r * E + e] = (v - mean) * rstd * gamma[e] + beta[e];
+    }
+}
+
+int layernorm_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta,
+                  float* y, int rows, int E, float eps, float pre_scale, hipStream_t st) {
+    if (!x || !gamma || !beta || !y || rows <= 0 || E <= 0 || (res && res_rows <= 0)) {
+        set_error("layernorm: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, res, res ? res_rows : 1,
+                       gamma, beta, y, rows, E, eps, pre_scale);
+    return launch_status("layernorm");
+}
+
+// ---------------------------------------------------------------- argmax over rows
+// idx[r * idx_stride] = first index of the maximum of logits[r][0..V)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int ld,
+                                                          long long* __restrict__ idx, int idx_stride, int V,
+                                                          float* __restrict__ top2gap) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ float s2[4];
+    const int r = blockIdx.x;
+    const float* row = logits + (size_t)r * ld;
+    float best = -INFINITY, second = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float x = row[v];
+        if (x > best) { second = best; best = x; bi = v; }
+        else if (x > second) second = x;
+    }
+    // wave reduce keeping the runner-up
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const float o2 = __shfl_xor(second, o, 64);
+        const float lose = (ov > best || (ov == best && oi < bi)) ? best : ov;
+        second = fmaxf(fmaxf(second, o2), lose);
+        argmax_combine(best, bi, ov, oi);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; s2[wave] = second; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = sv[0], sec = s2[0];
+        int i = si[0];
+        for (int w = 1; w < 4; ++w) {
+            const float ov = sv[w];
+            const int oi = si[w];
+            const float lose = (ov > b || (ov == b && oi < i)) ? b : ov;
+            sec = fmaxf(fmaxf(sec, s2[w]), lose);
+            argmax_combine(b, i, ov, oi);
+        }
+        idx[(size_t)r * idx_stride] = i;
+        if (top2gap) top2gap[r] = b - sec;
+    }
+}
+
+int argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_stride, int rows, int V,
+                    float* top2gap, hipStream_t st) {
+    if (!logits || !idx || rows <= 0 || V <= 0 || ld < V || idx_stride <= 0) { set_error("argmax_rows: bad arguments"); return ICAP_ERR_ARG; }
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, st, logits, ld, idx, idx_stride, V, top2gap);
+    return launch_status("argmax_rows");
+}
+
+// ---------------------------------------------------------------- multi-head attention core
+// q: [Lq][N][E]  k, v: [Lk][Nk][E] with Nk == N or Nk == 1 (keys shared by every
+// batch column).  out[lq][n][h*hd + d] = sum_s softmax_s(q.k_s / sqrt(hd)) v_s.
+// One wave per (lq, n, head); the softmax runs online over the keys.
+__global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, float* __restrict__ out,
+                                                       int Lq, int Lk, int N, int Nk, int E, int heads) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + wave;  // over Lq*N*heads
+    if (item >= (long long)Lq * N * heads) return;
+    const int h = (int)(item % heads);
+    const long long ln = item / heads;
+    const int n = (int)(ln % N);
+    const int hd = E / heads;
+    const float scaling = 1.0f / sqrtf((float)hd);
+    const float* qp = q + (size_t)ln * E + (size_t)h * hd;
+    const int nk = (Nk == 1) ? 0 : n;
+    constexpr int MAXD = 8;  // head_dim <= 512
+    float qr[MAXD], acc[MAXD];
+#pragma unroll
+    for (int i = 0; i < MAXD; ++i) {
+        const int d = lane + 64 * i;
+        qr[i] = (d < hd) ? qp[d] * scaling : 0.f;
+        acc[i] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int s = 0; s < Lk; ++s) {
+        const float* kp = k + ((size_t)s * Nk + nk) * E + (size_t)h * hd;
+        const float* vp = v + ((size_t)s * Nk + nk) * E + (size_t)h * hd;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) {
+            const int d = lane + 64 * i;
+            if (d < hd) dot = fmaf(qr[i], kp[d], dot);
+        }
+        dot = wave_sum(dot);
+        const float mn = fmaxf(m, dot);
+        const float corr = expf(m - mn);  // exp(-inf) = 0 on the first key
+        const float p = expf(dot - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) {
+            const int d = lane + 64 * i;
+            if (d < hd) acc[i] = fmaf(p, vp[d], acc[i] * corr);
+        }
+        m = mn;
+    }
+    const float inv = 1.0f / l;
+    float* op = out + (size_t)ln * E + (size_t)h * hd;
+#pragma unroll
+    for (int i = 0; i < MAXD; ++i) {
+        const int d = lane + 64 * i;
+        if (d < hd) op[d] = acc[i] * inv;
+    }
+}
+
+int mha_core_f32(const float* q, const float* k, const float* v, float* out, int Lq, int Lk, int N, int Nk,
+                 int E, int heads, hipStream_t st) {
+    if (!q || !k || !v || !out || Lq <= 0 || Lk <= 0 || N <= 0 || E <= 0 || heads <= 0 || E % heads ||
+        (Nk != N && Nk != 1)) {
+        set_error("mha_core: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (E / heads > 512) { set_error("mha_core: head_dim %d exceeds 512", E / heads); return ICAP_ERR_LIMIT; }
+    const long long items = (long long)Lq * N * heads;
+    const long long blocks = (items + 3) / 4;
+    if (blocks > 0x7fffffffLL) { set_error("mha_core: too large"); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(mha_core_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q, k, v, out, Lq, Lk, N, Nk, E, heads);
+    return launch_status("mha_core");
+}
+
+// ---------------------------------------------------------------- Bahdanau additive attention
+// score[i][j] = a_b + sum_a a_w[a] * tanh(u[j][a] + w[i][a]);  alpha[i][:] = softmax_j(score[i][:]);
+// context[i][:] = sum_j alpha[i][j] * feat[j][:].   One workgroup per query i.
+constexpr int BAH_MAX_B = 4096;
+
+__global__ __launch_bounds__(256) void bahdanau_attention_kernel(
+    const float* __restrict__ u, const float* __restrict__ w, const float* __restrict__ a_w, float a_b,
+    const float* __restrict__ feat, float* __restrict__ alpha, float* __restrict__ context, int B, int A, int E) {
+    __shared__ float sc[BAH_MAX_B];
+    __shared__ float redv[4];
+    const int i = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* wi = w + (size_t)i * A;
+    for (int j = wave; j < B; j += 4) {
+        const float* uj = u + (size_t)j * A;
+        float s = 0.f;
+        for (int a = lane; a < A; a += 64) s = fmaf(a_w[a], tanhf(uj[a] + wi[a]), s);
+        s = wave_sum(s);
+        if (lane == 0) sc[j] = s + a_b;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < B; j += 256) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    if (lane == 0) redv[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
+    __syncthreads();
+    float l = 0.f;
+    for (int j = threadIdx.x; j < B; j += 256) {
+        const float p = expf(sc[j] - m);
+        sc[j] = p;
+        l += p;
+    }
+    l = wave_sum(l);
+    if (lane == 0) redv[wave] = l;
+    __syncthreads();
+    const float inv = 1.0f / (((redv[0] + redv[1]) + redv[2]) + redv[3]);
+    for (int j = threadIdx.x; j < B; j += 256) {
+        const float p = sc[j] * inv;
+        sc[j] = p;
+        if (alpha) alpha[(size_t)i * B + j] = p;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) {
+        float c = 0.f;
+        for (int j = 0; j < B; ++j) c = fmaf(sc[j], feat[(size_t)j * E + e], c);
+        context[(size_t)i * E + e] = c;
+    }
+}
+
+int bahdanau_attention_f32(const float* u, const float* w, const float* a_w, float a_b, const float* feat,
+                           float* alpha, float* context, int B, int A, int E, hipStream_t st) {
+    if (!u || !w || !a_w || !feat || !context || B <= 0 || A <= 0 || E <= 0) { set_error("bahdanau_attention: bad arguments"); return ICAP_ERR_ARG; }
+    if (B > BAH_MAX_B) { set_error("bahdanau_attention: B=%d exceeds %d", B, BAH_MAX_B); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(bahdanau_attention_kernel, dim3(B), dim3(256), 0, st, u, w, a_w, a_b, feat, alpha, context, B, A, E);
+    return launch_status("bahdanau_attention");
+}
+
+// ---------------------------------------------------------------- recurrent gate non-linearities
+// LSTM: gates[b][4H] = (i, f, g, o) pre-activations with every bias already added.
+__global__ void lstm_pointwise_kernel(const float* __restrict__ gates, const float* __restrict__ c_in,
+                                      float* __restrict__ h_out, float* __restrict__ c_out, int H, long long total) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const long long b = t / H;
+    const int j = (int)(t - b * H);
+    const float* g = gates + (size_t)b * 4 * H;
+    const float ig = sigmoidf_(g[j]);
+    const float fg = sigmoidf_(g[H + j]);
+    const float gg = tanhf(g[2 * H + j]);
+    const float og = sigmoidf_(g[3 * H + j]);
+    const float c = fg * c_in[t] + ig * gg;
+    c_out[t] = c;
+    h_out[t] = og * tanhf(c);
+}
+
+int lstm_pointwise_f32(const float* gates, const float* c_in, float* h_out, float* c_out, int B, int H, hipStream_t st) {
+    if (!gates || !c_in || !h_out || !c_out || B <= 0 || H <= 0) { set_error("lstm_pointwise: bad arguments"); return ICAP_ERR_ARG; }
+    const long long total = (long long)B * H;
+    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gates, c_in, h_out, c_out, H, total);
+    return launch_status("lstm_pointwise");
+}
+
+// GRU: gi = W_ih x + b_ih, gh = W_hh h + b_hh, both [b][3H] in (r, z, n) order.
+__global__ void gru_pointwise_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                     const float* __restrict__ h_in, float* __restrict__ h_out, int H, long long total) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const long long b = t / H;
+    const int j = (int)(t - b * H);
+    const float* a = gi + (size_t)b * 3 * H;
+    const float* c = gh + (size_t)b * 3 * H;
+    const float r = sigmoidf_(a[j] + c[j]);
+    const float z = sigmoidf_(a[H + j] + c[H + j]);
+    const float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+    h_out[t] = (1.f - z) * n + z * h_in[t];
+}
+
+int gru_pointwise_f32(const float* gi, const float* gh, const float* h_in, float* h_out, int B, int H, hipStream_t st) {
+    if (!gi || !gh || !h_in || !h_out || B <= 0 || H <= 0) { set_error("gru_pointwise: bad arguments"); return ICAP_ERR_ARG; }
+    const long long total = (long long)B * H;
+    hipLaunchKernelGGL(gru_pointwise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gi, gh, h_in, h_out, H, total);
+    return launch_status("gru_pointwise");
+}
+
+}  // namespace icap

@@ -1,0 +1,286 @@
+// Bandwidth-bound spatial kernels of the CNN encoders (NHWC fp32):
+// layout change for the network input, depthwise convolution with fused
+// batch-norm + activation and deterministic partial pooling for squeeze-excite,
+// the squeeze-excite gate itself, max pooling and average pooling.
+// All of them move 16 bytes per lane per access along the channel axis.
+#include "common.hpp"
+
+namespace icap {
+
+// ---------------------------------------------------------------- layout
+// NCHW fp32 image -> NHWC with the channel axis zero-padded to Cp (Cp % 4 == 0),
+// so the first convolution can stage 16-byte channel groups like every other one.
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                        int C, int HW, int Cp, long long total_pix) {
+    const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW
+    if (pix >= total_pix) return;
+    const long long b = pix / HW;
+    const int s = (int)(pix - b * HW);
+    const float* sp = src + (size_t)b * C * HW + s;
+    float* dp = dst + (size_t)pix * Cp;
+    for (int c = 0; c < Cp; c += 4) {
+        float4 v;
+        v.x = (c + 0 < C) ? sp[(size_t)(c + 0) * HW] : 0.f;
+        v.y = (c + 1 < C) ? sp[(size_t)(c + 1) * HW] : 0.f;
+        v.z = (c + 2 < C) ? sp[(size_t)(c + 2) * HW] : 0.f;
+        v.w = (c + 3 < C) ? sp[(size_t)(c + 3) * HW] : 0.f;
+        *reinterpret_cast<float4*>(dp + c) = v;
+    }
+}
+
+int nchw_to_nhwc_pad_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, hipStream_t st) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || Cp % 4) {
+        set_error("nchw_to_nhwc_pad: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (!aligned16(dst)) { set_error("nchw_to_nhwc_pad: dst must be 16-byte aligned"); return ICAP_ERR_ALIGN; }
+    const long long total = (long long)B * H * W;
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) { set_error("nchw_to_nhwc_pad: too large"); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, C, H * W, Cp, total);
+    return launch_status("nchw_to_nhwc_pad");
+}
+
+// ---------------------------------------------------------------- depthwise conv
+// One workgroup covers a chunk of P output pixels of one image for all channels.
+// Thread (tx, py): channel quad tx, pixel lane py.  The per-channel sums over the
+// chunk (needed by squeeze-excite) are reduced across pixel lanes in a fixed order
+// and written to partial[b][chunk][C]; the gate kernel adds the chunks in order, so
+// the pooled value does not depend on scheduling.
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+    const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ partial, int H, int W,
+    int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, int P, int nqp_log2) {
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x;
+    const int nq = C >> 2;
+    const int NQP = 1 << nqp_log2;
+    const int PL = 256 >> nqp_log2;
+    const int tx = tid & (NQP - 1);
+    const int py = tid >> nqp_log2;
+    const int b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int nchunks = gridDim.x;
+    const int HoWo = Ho * Wo;
+    const int pix_begin = chunk * P;
+    const int pix_end = min(pix_begin + P, HoWo);
+    const float* xb = x + (size_t)b * H * W * C;
+    float* yb = y + (size_t)b * HoWo * C;
+    float* pb = partial ? partial + ((size_t)b * nchunks + chunk) * C : nullptr;
+
+    for (int cq = tx; cq < nq; cq += NQP) {
+        const int c = cq << 2;
+        const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 bi = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 wreg[KS * KS];
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) wreg[t] = *reinterpret_cast<const float4*>(w + (size_t)t * C + c);
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int pix = pix_begin + py; pix < pix_end; pix += PL) {
+            const int ho = pix / Wo, wo = pix - ho * Wo;
+            const int hi0 = ho * stride - pad_t, wi0 = wo * stride - pad_l;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < KS; ++r) {
+                const int hi = hi0 + r;
+                if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+                for (int q = 0; q < KS; ++q) {
+                    const int wi = wi0 + q;
+                    if ((unsigned)wi >= (unsigned)W) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)hi * W + wi) * C + c);
+                    const float4 k = wreg[r * KS + q];
+                    a.x = fmaf(v.x, k.x, a.x); a.y = fmaf(v.y, k.y, a.y);
+                    a.z = fmaf(v.z, k.z, a.z); a.w = fmaf(v.w, k.w, a.w);
+                }
+            }
+            float4 o;
+            o.x = act_apply(fmaf(a.x, sc.x, bi.x), act); o.y = act_apply(fmaf(a.y, sc.y, bi.y), act);
+            o.z = act_apply(fmaf(a.z, sc.z, bi.z), act); o.w = act_apply(fmaf(a.w, sc.w, bi.w), act);
+            *reinterpret_cast<float4*>(yb + (size_t)pix * C + c) = o;
+            sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+        }
+        if (PL == 1) {
+            if (pb) *reinterpret_cast<float4*>(pb + c) = sum;
+        } else {
+            red[tid] = sum;  // with PL > 1 every thread runs this loop body at most once
+        }
+    }
+    if (PL > 1 && pb) {
+        __syncthreads();
+        if (py == 0 && tx < nq) {
+            float4 s = red[tx];
+            for (int l = 1; l < PL; ++l) {
+                const float4 o = red[(l << nqp_log2) + tx];
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+            *reinterpret_cast<float4*>(pb + (tx << 2)) = s;
+        }
+    }
+}
+
+int dwconv_chunks(int Ho, int Wo, int* P_out) {
+    // 64 output pixels per workgroup keeps >1k workgroups in flight on the large
+    // early layers and a single chunk on the 7x7 tail.
+    const int P = 64;
+    if (P_out) *P_out = P;
+    return (Ho * Wo + P - 1) / P;
+}
+
+int dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                 float* partial, int B, int H, int W, int C, int KS, int stride, int pad_t, int pad_l,
+                 int Ho, int Wo, int act, hipStream_t st) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || stride <= 0 || Ho <= 0 || Wo <= 0) {
+        set_error("dwconv2d: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (C % 4) { set_error("dwconv2d: C=%d must be a multiple of 4", C); return ICAP_ERR_ALIGN; }
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (partial && !aligned16(partial)) ||
+        (scale && !aligned16(scale)) || (bias && !aligned16(bias))) {
+        set_error("dwconv2d: pointers must be 16-byte aligned");
+        return ICAP_ERR_ALIGN;
+    }
+    if (B > 65535) { set_error("dwconv2d: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
+    int P;
+    const int nchunks = dwconv_chunks(Ho, Wo, &P);
+    const int nq = C / 4;
+    int lg = 0;
+    while ((1 << lg) < nq && lg < 8) ++lg;
+    dim3 grid(nchunks, B), block(256);
+    if (KS == 3)
+        hipLaunchKernelGGL(dwconv_kernel<3>, grid, block, 0, st, x, w, scale, bias, y, partial, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, P, lg);
+    else if (KS == 5)
+        hipLaunchKernelGGL(dwconv_kernel<5>, grid, block, 0, st, x, w, scale, bias, y, partial, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, P, lg);
+    else { set_error("dwconv2d: kernel size %d not supported (3 or 5)", KS); return ICAP_ERR_ARG; }
+    return launch_status("dwconv2d");
+}
+
+// ---------------------------------------------------------------- squeeze-excite gate
+// One workgroup per image: pooled = sum of chunk partials / HW; s = swish(Wr pooled + br);
+// gate = sigmoid(We s + be).
+constexpr int SE_MAX_C = 2048;
+constexpr int SE_MAX_S = 128;
+
+__global__ __launch_bounds__(256) void se_gate_kernel(
+    const float* __restrict__ partial, int nchunks, float inv_hw, const float* __restrict__ wr,
+    const float* __restrict__ br, const float* __restrict__ we, const float* __restrict__ be,
+    float* __restrict__ gate, int C, int S) {
+    __shared__ float pooled[SE_MAX_C];
+    __shared__ float sq[SE_MAX_S];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* pb = partial + (size_t)b * nchunks * C;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < nchunks; ++k) s += pb[(size_t)k * C + c];
+        pooled[c] = s * inv_hw;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int j = wave; j < S; j += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(wr[(size_t)j * C + c], pooled[c], a);
+        a = wave_sum(a);
+        if (lane == 0) sq[j] = act_apply(a + br[j], ACT_SWISH);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = be[c];
+        for (int j = 0; j < S; ++j) a = fmaf(we[(size_t)c * S + j], sq[j], a);
+        gate[(size_t)b * C + c] = sigmoidf_(a);
+    }
+}
+
+int se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr, const float* br,
+                const float* we, const float* be, float* gate, int B, int C, int S, hipStream_t st) {
+    if (!partial || !wr || !br || !we || !be || !gate || B <= 0 || C <= 0 || S <= 0 || nchunks <= 0) {
+        set_error("se_gate: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (C > SE_MAX_C || S > SE_MAX_S) { set_error("se_gate: C=%d S=%d exceed %d/%d", C, S, SE_MAX_C, SE_MAX_S); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), 0, st, partial, nchunks, inv_hw, wr, br, we, be, gate, C, S);
+    return launch_status("se_gate");
+}
+
+// ---------------------------------------------------------------- max pooling
+__global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                               int KS, int stride, int pad, int Ho, int Wo, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*Ho*Wo*(C/4)
+    if (i >= total) return;
+    const int nq = C >> 2;
+    const int cq = (int)(i % nq);
+    long long pix = i / nq;
+    const int wo = (int)(pix % Wo); pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const long long b = pix / Ho;
+    const float* xb = x + (size_t)b * H * W * C + (cq << 2);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int r = 0; r < KS; ++r) {
+        const int hi = ho * stride - pad + r;
+        if ((unsigned)hi >= (unsigned)H) continue;
+        for (int q = 0; q < KS; ++q) {
+            const int wi = wo * stride - pad + q;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)hi * W + wi) * C);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<float4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * C + (cq << 2)) = m;
+}
+
+int maxpool2d_f32(const float* x, float* y, int B, int H, int W, int C, int KS, int stride, int pad,
+                  int Ho, int Wo, hipStream_t st) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || KS <= 0 || stride <= 0 || pad < 0 || Ho <= 0 || Wo <= 0) {
+        set_error("maxpool2d: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (C % 4 || !aligned16(x) || !aligned16(y)) { set_error("maxpool2d: C %% 4 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
+    if (pad * 2 > KS) { set_error("maxpool2d: pad larger than half the window"); return ICAP_ERR_ARG; }
+    const long long total = (long long)B * Ho * Wo * (C / 4);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) { set_error("maxpool2d: too large"); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, H, W, C, KS, stride, pad, Ho, Wo, total);
+    return launch_status("maxpool2d");
+}
+
+// ---------------------------------------------------------------- average pooling
+// Adaptive average pooling NHWC -> [B, OH, OW, C] with torch's window rule
+// start = floor(i*H/OH), end = ceil((i+1)*H/OH).  OH = OW = 1 is global pooling.
+__global__ void adaptive_avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                        int C, int OH, int OW, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*OH*OW*(C/4)
+    if (i >= total) return;
+    const int nq = C >> 2;
+    const int cq = (int)(i % nq);
+    long long pix = i / nq;
+    const int ow = (int)(pix % OW); pix /= OW;
+    const int oh = (int)(pix % OH);
+    const long long b = pix / OH;
+    const int h0 = (oh * H) / OH, h1 = ((oh + 1) * H + OH - 1) / OH;
+    const int w0 = (ow * W) / OW, w1 = ((ow + 1) * W + OW - 1) / OW;
+    const float* xb = x + (size_t)b * H * W * C + (cq << 2);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = h0; h < h1; ++h)
+        for (int w_ = w0; w_ < w1; ++w_) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)h * W + w_) * C);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+    s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+    *reinterpret_cast<float4*>(y + (((size_t)b * OH + oh) * OW + ow) * C + (cq << 2)) = s;
+}
+
+int adaptive_avgpool2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, hipStream_t st) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) {
+        set_error("adaptive_avgpool2d: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (C % 4 || !aligned16(x) || !aligned16(y)) { set_error("adaptive_avgpool2d: C %% 4 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
+    const long long total = (long long)B * OH * OW * (C / 4);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) { set_error("adaptive_avgpool2d: too large"); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, H, W, C, OH, OW, total);
+    return launch_status("adaptive_avgpool2d");
+}
+
+}  // namespace icap

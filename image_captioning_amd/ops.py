@@ -1,0 +1,309 @@
+"""Tensor-level wrappers over the C ABI.
+
+PyTorch is used for device memory and the current HIP stream only; every
+arithmetic operation below runs in ``libicap_hip.so``.  Inputs must live on a HIP
+device (``tensor.is_cuda``), be fp32 and contiguous - anything else raises, there
+is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from ._native import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, ACT_TANH, IcapError  # noqa: F401
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ck(t: torch.Tensor | None, name: str, dtype=torch.float32):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise IcapError(f"{name}: expected a tensor on the HIP device, got {getattr(t, 'device', type(t))}; "
+                        "the MI355X path has no CPU fallback")
+    if t.dtype != dtype:
+        raise IcapError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise IcapError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def conv_out_size(size: int, k: int, stride: int, pad_lo: int, pad_hi: int) -> int:
+    return (size + pad_lo + pad_hi - k) // stride + 1
+
+
+def nchw_to_nhwc_pad(images: torch.Tensor, cp: int = 4) -> torch.Tensor:
+    B, Cc, H, W = images.shape
+    out = torch.empty((B, H, W, cp), device=images.device, dtype=torch.float32)
+    N.check(N.load().icap_nchw_to_nhwc_pad_f32(_ck(images, "images"), _ck(out, "out"), B, Cc, H, W, cp, _stream()),
+            "nchw_to_nhwc_pad")
+    return out
+
+
+def conv2d(x, w, scale=None, bias=None, residual=None, gate=None, *, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, out=None):
+    """x [B,H,W,Cin] NHWC, w [Cout,KH,KW,Cin]; pad = (top, bottom, left, right)."""
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, Cin2 = w.shape
+    if Cin2 != Cin:
+        raise IcapError(f"conv2d: weight expects {Cin2} input channels, activation has {Cin}")
+    pt, pb, pl, pr = pad
+    Ho = conv_out_size(H, KH, stride, pt, pb)
+    Wo = conv_out_size(W, KW, stride, pl, pr)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    elif out.numel() != B * Ho * Wo * Cout:
+        raise IcapError("conv2d: out has the wrong size")
+    if residual is not None and residual.numel() != out.numel():
+        raise IcapError("conv2d: residual has the wrong size")
+    if gate is not None and tuple(gate.shape) != (B, Cin):
+        raise IcapError("conv2d: gate must be [B, Cin]")
+    for v, nm in ((scale, "scale"), (bias, "bias")):
+        if v is not None and v.numel() != Cout:
+            raise IcapError(f"conv2d: {nm} must have Cout={Cout} elements")
+    N.check(N.load().icap_conv2d_f32(
+        _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"),
+        _ck(gate, "gate"), _ck(out, "out"), B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo, act, _stream()), "conv2d")
+    return out
+
+
+def linear(x, w, bias=None, scale=None, act=ACT_NONE, residual=None, out=None):
+    """y[M,N] = act((x[M,K] @ w[N,K]^T) * scale + bias (+ residual)) on the matrix cores."""
+    M, K = x.shape
+    Nn, K2 = w.shape
+    if K != K2:
+        raise IcapError(f"linear: x has K={K}, w has K={K2}")
+    if out is None:
+        out = torch.empty((M, Nn), device=x.device, dtype=torch.float32)
+    if residual is not None and residual.numel() != M * Nn:
+        raise IcapError("linear: residual has the wrong size")
+    N.check(N.load().icap_conv2d_f32(
+        _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"), None,
+        _ck(out, "out"), M, 1, 1, K, Nn, 1, 1, 1, 0, 0, 1, 1, act, _stream()), "linear")
+    return out
+
+
+def dwconv2d(x, w, scale=None, bias=None, *, ks, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, want_partial=False):
+    """x [B,H,W,C], w [ks*ks, C] -> (y, partial or None)."""
+    B, H, W, Cc = x.shape
+    pt, pb, pl, pr = pad
+    Ho = conv_out_size(H, ks, stride, pt, pb)
+    Wo = conv_out_size(W, ks, stride, pl, pr)
+    if tuple(w.shape) != (ks * ks, Cc):
+        raise IcapError("dwconv2d: weight must be [ks*ks, C]")
+    y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    lib = N.load()
+    partial = None
+    if want_partial:
+        partial = torch.empty((B, lib.icap_dwconv_chunks(Ho, Wo), Cc), device=x.device, dtype=torch.float32)
+    N.check(lib.icap_dwconv2d_f32(_ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(y, "y"),
+                                  _ck(partial, "partial"), B, H, W, Cc, ks, stride, pt, pl, Ho, Wo, act, _stream()),
+            "dwconv2d")
+    return y, partial
+
+
+def se_gate(partial, hw: int, wr, br, we, be):
+    B, nchunks, Cc = partial.shape
+    S = wr.shape[0]
+    if tuple(wr.shape) != (S, Cc) or tuple(we.shape) != (Cc, S) or br.numel() != S or be.numel() != Cc:
+        raise IcapError("se_gate: weight shapes do not match")
+    gate = torch.empty((B, Cc), device=partial.device, dtype=torch.float32)
+    N.check(N.load().icap_se_gate_f32(_ck(partial, "partial"), nchunks, 1.0 / hw, _ck(wr, "wr"), _ck(br, "br"),
+                                      _ck(we, "we"), _ck(be, "be"), _ck(gate, "gate"), B, Cc, S, _stream()), "se_gate")
+    return gate
+
+
+def maxpool2d(x, ks, stride, pad):
+    B, H, W, Cc = x.shape
+    Ho = conv_out_size(H, ks, stride, pad, pad)
+    Wo = conv_out_size(W, ks, stride, pad, pad)
+    y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    N.check(N.load().icap_maxpool2d_f32(_ck(x, "x"), _ck(y, "y"), B, H, W, Cc, ks, stride, pad, Ho, Wo, _stream()), "maxpool2d")
+    return y
+
+
+def adaptive_avgpool2d(x, oh, ow):
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, oh, ow, Cc), device=x.device, dtype=torch.float32)
+    N.check(N.load().icap_adaptive_avgpool2d_f32(_ck(x, "x"), _ck(y, "y"), B, H, W, Cc, oh, ow, _stream()), "adaptive_avgpool2d")
+    return y
+
+
+def embedding(table, idx, add=None):
+    V, E = table.shape
+    rows = idx.numel()
+    out = torch.empty((rows, E), device=table.device, dtype=torch.float32)
+    err = torch.zeros(1, device=table.device, dtype=torch.int32)
+    if add is not None and add.numel() != rows * E:
+        raise IcapError("embedding: add must be [rows, E]")
+    N.check(N.load().icap_embedding_f32(_ck(table, "table"), _ck(idx, "idx", torch.int64), _ck(add, "add"), _ck(out, "out"),
+                                        rows, E, V, _ck(err, "err", torch.int32), _stream()), "embedding")
+    return out, err
+
+
+def layernorm(x, gamma, beta, res=None, eps=1e-5, pre_scale=1.0):
+    rows, E = x.shape
+    res_rows = 1
+    if res is not None:
+        if res.shape[-1] != E or rows % (res.numel() // E):
+            raise IcapError("layernorm: residual rows must divide x rows")
+        res_rows = res.numel() // E
+    y = torch.empty_like(x)
+    N.check(N.load().icap_layernorm_f32(_ck(x, "x"), _ck(res, "res"), res_rows, _ck(gamma, "gamma"), _ck(beta, "beta"),
+                                        _ck(y, "y"), rows, E, eps, pre_scale, _stream()), "layernorm")
+    return y
+
+
+def argmax_rows(logits, want_gap=False):
+    rows, V = logits.shape
+    idx = torch.empty(rows, device=logits.device, dtype=torch.int64)
+    gap = torch.empty(rows, device=logits.device, dtype=torch.float32) if want_gap else None
+    N.check(N.load().icap_argmax_rows_f32(_ck(logits, "logits"), V, _ck(idx, "idx", torch.int64), 1, rows, V,
+                                          _ck(gap, "gap"), _stream()), "argmax_rows")
+    return (idx, gap) if want_gap else idx
+
+
+def mha_core(q, k, v, heads):
+    """q [Lq,N,E]; k, v [Lk,Nk,E] with Nk in (N, 1)."""
+    Lq, Nn, E = q.shape
+    Lk, Nk, E2 = k.shape
+    if E2 != E or tuple(v.shape) != tuple(k.shape):
+        raise IcapError("mha_core: shape mismatch")
+    out = torch.empty_like(q)
+    N.check(N.load().icap_mha_core_f32(_ck(q, "q"), _ck(k, "k"), _ck(v, "v"), _ck(out, "out"), Lq, Lk, Nn, Nk, E, heads,
+                                       _stream()), "mha_core")
+    return out
+
+
+def bahdanau_attention(u, w, a_w, a_b: float, feat, want_alpha=True):
+    B, A = u.shape
+    E = feat.shape[-1]
+    if tuple(w.shape) != (B, A) or a_w.numel() != A or feat.numel() != B * E:
+        raise IcapError("bahdanau_attention: shape mismatch")
+    alpha = torch.empty((B, B), device=u.device, dtype=torch.float32) if want_alpha else None
+    ctx = torch.empty((B, E), device=u.device, dtype=torch.float32)
+    N.check(N.load().icap_bahdanau_attention_f32(_ck(u, "u"), _ck(w, "w"), _ck(a_w, "a_w"), float(a_b), _ck(feat, "feat"),
+                                                 _ck(alpha, "alpha"), _ck(ctx, "ctx"), B, A, E, _stream()), "bahdanau_attention")
+    return alpha, ctx
+
+
+def lstm_pointwise(gates, c_in):
+    B, H4 = gates.shape
+    H = H4 // 4
+    h = torch.empty((B, H), device=gates.device, dtype=torch.float32)
+    c = torch.empty((B, H), device=gates.device, dtype=torch.float32)
+    N.check(N.load().icap_lstm_pointwise_f32(_ck(gates, "gates"), _ck(c_in, "c_in"), _ck(h, "h"), _ck(c, "c"), B, H, _stream()),
+            "lstm_pointwise")
+    return h, c
+
+
+def gru_pointwise(gi, gh, h_in):
+    B, H3 = gi.shape
+    H = H3 // 3
+    h = torch.empty((B, H), device=gi.device, dtype=torch.float32)
+    N.check(N.load().icap_gru_pointwise_f32(_ck(gi, "gi"), _ck(gh, "gh"), _ck(h_in, "h_in"), _ck(h, "h"), B, H, _stream()),
+            "gru_pointwise")
+    return h
+
+
+def gemv(W, x, bias=None, scale=None, act=ACT_NONE, want_partials=False):
+    """x [NB<=8, K], W [N, K] -> y [NB, N] (and arg-max partials when asked)."""
+    NB, K = x.shape
+    Nn = W.shape[0]
+    lib = N.load()
+    y = torch.empty((NB, Nn), device=x.device, dtype=torch.float32)
+    pv = pi = None
+    if want_partials:
+        P = lib.icap_gemv_blocks(Nn)
+        pv = torch.empty((NB, P), device=x.device, dtype=torch.float32)
+        pi = torch.empty((NB, P), device=x.device, dtype=torch.int32)
+    N.check(lib.icap_gemv_f32(_ck(W, "W"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(x, "x"), K, _ck(y, "y"), Nn, NB, Nn, K,
+                              act, _ck(pv, "pv"), _ck(pi, "pi", torch.int32), _stream()), "gemv")
+    return (y, pv, pi) if want_partials else y
+
+
+def lstm_cell(w_ih, w_hh, b_ih, b_hh, x, h, c):
+    NB, I = x.shape
+    H = h.shape[1]
+    ho, co = torch.empty_like(h), torch.empty_like(c)
+    N.check(N.load().icap_lstm_cell_f32(_ck(w_ih, "w_ih"), _ck(w_hh, "w_hh"), _ck(b_ih, "b_ih"), _ck(b_hh, "b_hh"),
+                                        _ck(x, "x"), I, _ck(h, "h"), _ck(c, "c"), _ck(ho, "ho"), _ck(co, "co"), NB, I, H,
+                                        _stream()), "lstm_cell")
+    return ho, co
+
+
+def gru_cell(w_ih, w_hh, b_ih, b_hh, x, h):
+    NB, I = x.shape
+    H = h.shape[1]
+    ho = torch.empty_like(h)
+    N.check(N.load().icap_gru_cell_f32(_ck(w_ih, "w_ih"), _ck(w_hh, "w_hh"), _ck(b_ih, "b_ih"), _ck(b_hh, "b_hh"),
+                                       _ck(x, "x"), I, _ck(h, "h"), _ck(ho, "ho"), NB, I, H, _stream()), "gru_cell")
+    return ho
+
+
+# ---------------------------------------------------------------- greedy drivers
+def _ptr(t):
+    return C.c_void_p(_ck(t, "weight"))
+
+
+def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False):
+    """wd: dict with is_lstm, w_ih/w_hh/b_ih/b_hh lists, fc_w, fc_b, in_table.  x0 [NB, I]."""
+    lib = N.load()
+    NB, I = x0.shape
+    L = len(wd["w_ih"])
+    H = wd["w_hh"][0].shape[1]
+    V = wd["fc_w"].shape[0]
+    w = N.RnnWeights()
+    w.layers, w.H, w.I, w.V, w.is_lstm = L, H, I, V, int(wd["is_lstm"])
+    for l in range(L):
+        w.w_ih[l] = _ck(wd["w_ih"][l], "w_ih"); w.w_hh[l] = _ck(wd["w_hh"][l], "w_hh")
+        w.b_ih[l] = _ck(wd["b_ih"][l], "b_ih"); w.b_hh[l] = _ck(wd["b_hh"][l], "b_hh")
+    w.fc_w, w.fc_b, w.in_table = _ck(wd["fc_w"], "fc_w"), _ck(wd["fc_b"], "fc_b"), _ck(wd["in_table"], "in_table")
+    dev = x0.device
+    ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+    logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+    ws = torch.empty(lib.icap_greedy_rnn_ws_floats(NB, L, H, I, V), device=dev, dtype=torch.float32)
+    N.check(lib.icap_greedy_rnn_f32(C.byref(w), _ck(x0, "x0"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"),
+                                    _ck(ws, "ws"), NB, steps, _stream()), "greedy_rnn")
+    return ids, logits
+
+
+def greedy_tfm(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False):
+    lib = N.load()
+    NB, E = ca.shape
+    FF = wd["fc1_w"].shape[0]
+    V = wd["out_w"].shape[0]
+    w = N.TfmWeights()
+    w.E, w.FF, w.V = E, FF, V
+    for k in ("emb", "ln2_g", "ln2_b", "ln3_g", "ln3_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "out_w", "out_b"):
+        setattr(w, k, _ck(wd[k], k))
+    dev = ca.device
+    ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+    logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+    ws = torch.empty(lib.icap_greedy_tfm_ws_floats(NB, E, FF, V), device=dev, dtype=torch.float32)
+    N.check(lib.icap_greedy_tfm_f32(C.byref(w), _ck(ca, "ca"), _ck(start_ids, "start_ids", torch.int64),
+                                    _ck(ids, "ids", torch.int64), _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()),
+            "greedy_tfm")
+    return ids, logits
+
+
+def greedy_bah(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False):
+    lib = N.load()
+    NB, ENC = context.shape
+    V, E = wd["emb"].shape
+    H = wd["w_hh"].shape[1]
+    w = N.BahWeights()
+    w.E, w.H, w.V = E, H, V
+    for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "fc_w", "fc_scale", "fc_bias"):
+        setattr(w, k, _ck(wd[k], k))
+    dev = context.device
+    ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+    logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+    ws = torch.empty(lib.icap_greedy_bah_ws_floats(NB, E, ENC, H, V), device=dev, dtype=torch.float32)
+    N.check(lib.icap_greedy_bah_f32(C.byref(w), _ck(context, "context"), ENC, _ck(start_ids, "start_ids", torch.int64),
+                                    _ck(ids, "ids", torch.int64), _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()),
+            "greedy_bah")
+    return ids, logits

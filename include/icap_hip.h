@@ -1,0 +1,206 @@
+/*
+ * icap_hip.h - C ABI of libicap_hip.so: the gfx950 (MI355X) kernels behind the
+ * captioning hot path of Merumalady/Image_Captioning (CNN encoder forward and the
+ * per-step decoder forward of its four models).
+ *
+ * The reference is pure Python on torch.nn and has no FFI of its own; each entry
+ * point below names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every tensor argument is a raw DEVICE pointer owned by the caller; the
+ *     library never allocates, frees or retains caller memory, workspaces are
+ *     passed in;
+ *   - fp32 everywhere, token ids are int64 (long long), activations of the CNN are
+ *     NHWC, channel counts are multiples of 4 and pointers 16-byte aligned;
+ *   - sizes are int (elements), `stream` is a hipStream_t passed as void*;
+ *   - calls only enqueue work on `stream` (no synchronisation, no host copies),
+ *     so they may be issued from any host thread that has set the device;
+ *   - return value 0 = ok, 1 = bad argument, 2 = alignment, 3 = size limit,
+ *     1000 + hipError_t = launch failure.  icap_last_error() returns a message for
+ *     the calling thread's most recent non-zero return.  Nothing throws.
+ */
+#ifndef ICAP_HIP_H
+#define ICAP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICAP_ABI_VERSION 1
+
+/* activation codes */
+#define ICAP_ACT_NONE 0
+#define ICAP_ACT_RELU 1
+#define ICAP_ACT_SWISH 2
+#define ICAP_ACT_SIGMOID 3
+#define ICAP_ACT_TANH 4
+
+int icap_abi_version(void);
+const char* icap_last_error(void);
+
+/* ------------------------------------------------------------------ encoder */
+
+/* NCHW image batch -> NHWC with channels zero-padded to Cp (Cp % 4 == 0).
+ * Replaces the implicit layout of `images` entering the backbone:
+ * seq2seqbasic.py:42, transformer_word_level.py:94. */
+int icap_nchw_to_nhwc_pad_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream);
+
+/* Convolution / Linear as implicit GEMM on the matrix cores:
+ *   y = act(conv(x * gate, w) * scale + bias + residual)
+ * x [B,H,W,Cin] NHWC, w [Cout,KH,KW,Cin], scale/bias [Cout] (folded BatchNorm or
+ * the layer bias; NULL = 1 / 0), residual [B,Ho,Wo,Cout] or NULL, gate [B,Cin]
+ * (squeeze-excite scale) or NULL.  Bottom/right padding is implied by Ho, Wo.
+ * Replaces torchvision resnet18 / vgg16 convolutions (seq2seqbasic.py:23-34,42),
+ * EfficientNet-B0 stem, expand, project and head convolutions
+ * (transformer_word_level.py:13,94) and every nn.Linear on the path when called
+ * with H = W = KH = KW = 1 (seq2seqbasic.py:43,63,65; transformer_word_level.py:21,
+ * 35,38,63,66,69; transformer_word_level_bahdnau.py:98-100,122). */
+int icap_conv2d_f32(const float* x, const float* w, const float* scale, const float* bias,
+                    const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
+                    int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                    void* stream);
+
+/* Depthwise KSxKS convolution (KS = 3 or 5) with fused scale/bias (folded
+ * BatchNorm) and activation.  w is [KS*KS][C].  When `partial` is not NULL it
+ * receives per-chunk channel sums of the OUTPUT, [B][icap_dwconv_chunks(Ho,Wo)][C],
+ * for the squeeze-excite pooling.  Replaces MBConv `_depthwise_conv` + `_bn1` +
+ * swish of EfficientNet-B0 (transformer_word_level.py:13). */
+int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                      float* partial, int B, int H, int W, int C, int KS, int stride, int pad_t, int pad_l,
+                      int Ho, int Wo, int act, void* stream);
+int icap_dwconv_chunks(int Ho, int Wo);
+
+/* Squeeze-excite gate: gate[b][c] = sigmoid(We . swish(Wr . mean_hw(x) + br) + be),
+ * from the chunk sums written by icap_dwconv2d_f32.  wr [S][C], we [C][S].
+ * Replaces MBConv `_se_reduce` / `_se_expand` (transformer_word_level.py:13). */
+int icap_se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr, const float* br,
+                     const float* we, const float* be, float* gate, int B, int C, int S, void* stream);
+
+/* Max pooling, square window, symmetric padding (resnet18 maxpool 3/2/1, vgg16
+ * 2/2/0: seq2seqbasic.py:24,33). */
+int icap_maxpool2d_f32(const float* x, float* y, int B, int H, int W, int C, int KS, int stride, int pad,
+                       int Ho, int Wo, void* stream);
+
+/* Adaptive average pooling to OH x OW (1x1 = global pool of resnet18 /
+ * EfficientNet-B0, 7x7 for vgg16: seq2seqbasic.py:24,34). */
+int icap_adaptive_avgpool2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, void* stream);
+
+/* ------------------------------------------------------------------ decoder rows */
+
+/* out[r] = table[idx[r]] (+ add[r]).  *err_flag is set to 1 on an out-of-range id.
+ * nn.Embedding: seq2seqbasic.py:61,88; transformer_word_level.py:105;
+ * transformer_word_level_bahdnau.py:133. */
+int icap_embedding_f32(const float* table, const long long* idx, const float* add, float* out, int rows,
+                       int E, int V, int* err_flag, void* stream);
+
+/* y[r] = LayerNorm(x[r] * pre_scale + res[r % res_rows]) * gamma + beta.
+ * transformer_word_level.py:46,48,75,77; transformer_word_level_bahdnau.py:77,88. */
+int icap_layernorm_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta,
+                       float* y, int rows, int E, float eps, float pre_scale, void* stream);
+
+/* idx[r*idx_stride] = argmax(logits[r][0..V)) (first maximum); top2gap[r] (optional)
+ * = best - runner-up.  seq2seqbasic.py:81 and the greedy form of TransformerTest.py:147-157. */
+int icap_argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_stride, int rows, int V,
+                         float* top2gap, void* stream);
+
+/* Scaled-dot-product attention after the input projections, sequence-first layout:
+ * q [Lq][N][E], k/v [Lk][Nk][E] with Nk = N or 1.  nn.MultiheadAttention core:
+ * transformer_word_level.py:45,74; transformer_word_level_bahdnau.py:74. */
+int icap_mha_core_f32(const float* q, const float* k, const float* v, float* out, int Lq, int Lk, int N,
+                      int Nk, int E, int heads, void* stream);
+
+/* Additive attention over the images of a batch: u = U(features) [B][A],
+ * w = W(hidden) [B][A]; alpha [B][B] (optional), context [B][E].
+ * transformer_word_level_bahdnau.py:102-110. */
+int icap_bahdanau_attention_f32(const float* u, const float* w, const float* a_w, float a_b, const float* feat,
+                                float* alpha, float* context, int B, int A, int E, void* stream);
+
+/* Gate non-linearities after a batched gate GEMM.  LSTM gates [B][4H] (i,f,g,o,
+ * biases included); GRU gi/gh [B][3H] (r,z,n).  torch.nn.LSTM/GRU/LSTMCell:
+ * seq2seqbasic.py:54,56,64,79; transformer_word_level_bahdnau.py:119,136. */
+int icap_lstm_pointwise_f32(const float* gates, const float* c_in, float* h_out, float* c_out, int B, int H, void* stream);
+int icap_gru_pointwise_f32(const float* gi, const float* gh, const float* h_in, float* h_out, int B, int H, void* stream);
+
+/* ------------------------------------------------------------------ decoder, small-batch weight streaming */
+
+/* y[b][n] = act((W[n,:].x[b,:]) * scale[n] + bias[n]) for NB <= 8 rows of x.
+ * With part_val/part_idx not NULL also writes per-workgroup arg-max partials
+ * [NB][icap_gemv_blocks(N)] (y may then be NULL).  Linear layers of one decode
+ * step: seq2seqbasic.py:80,89; transformer_word_level.py:76,78. */
+int icap_gemv_f32(const float* W, const float* scale, const float* bias, const float* x, int ldx, float* y,
+                  int ldy, int NB, int N, int K, int act, float* part_val, int* part_idx, void* stream);
+int icap_gemv_blocks(int N);
+
+/* Reduce arg-max partials to ids[b*ids_stride]; optionally gather the next input
+ * row next_x[b] = table[id] (+ add[b]).  seq2seqbasic.py:81,88-89. */
+int icap_argmax_finalize_f32(const float* part_val, const int* part_idx, int nparts, long long* ids,
+                             int ids_stride, const float* table, const float* add, float* next_x, int ldx,
+                             int E, int NB, void* stream);
+
+/* One LSTM / GRU cell step for NB <= 8 sequences, weights in torch layout
+ * ([4H or 3H][I], [4H or 3H][H], two bias vectors).  h_out must not alias h_in.
+ * seq2seqbasic.py:79; transformer_word_level_bahdnau.py:136. */
+int icap_lstm_cell_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                       const float* x, int ldx, const float* h_in, const float* c_in, float* h_out,
+                       float* c_out, int NB, int I, int H, void* stream);
+int icap_gru_cell_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                      const float* x, int ldx, const float* h_in, float* h_out, int NB, int I, int H,
+                      void* stream);
+
+/* ------------------------------------------------------------------ greedy drivers
+ * Each enqueues `steps` decode steps for NB <= 8 captions in lock-step without any
+ * host synchronisation; ids [NB][steps] receives every step's token (the caller cuts
+ * at the end token).  logits_out (optional) [steps][NB][V] receives every step's
+ * logits.  All pointers in the descriptor structs are device pointers. */
+
+typedef struct {
+    int layers, H, I, V, is_lstm;            /* I = input width of layer 0 */
+    const float* w_ih[4]; const float* w_hh[4]; const float* b_ih[4]; const float* b_hh[4];
+    const float* fc_w; const float* fc_b;    /* [V][H], [V] */
+    const float* in_table;                   /* [V][I]: feature_fc(embed) rows */
+} icap_rnn_weights;
+
+/* DecoderRNN.sample (seq2seqbasic.py:68-91).  x0 [NB][I] is feature_fc(features).
+ * ws: float workspace, icap_greedy_rnn_ws_floats(NB, layers, H, I, V) floats. */
+int icap_greedy_rnn_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, float* ws,
+                        int NB, int steps, void* stream);
+long long icap_greedy_rnn_ws_floats(int NB, int layers, int H, int I, int V);
+
+typedef struct {
+    int E, FF, V;
+    const float* emb;                        /* caption_embedding [V][E] */
+    const float* ln2_g; const float* ln2_b; const float* ln3_g; const float* ln3_b;
+    const float* fc1_w; const float* fc1_b;  /* [FF][E] */
+    const float* fc2_w; const float* fc2_b;  /* [E][FF] */
+    const float* out_w; const float* out_b;  /* [V][E] */
+} icap_tfm_weights;
+
+/* Greedy form of generate_caption for the word / char transformer
+ * (TransformerTest.py:139-164 over transformer_word_level.py:72-79): position t's
+ * logits depend only on token t and the image, so one step is
+ * LN2(emb[tok] + ca) -> FFN -> LN3 -> output_fc -> argmax.  ca [NB][E] is the
+ * per-image cross-attention output.  start_ids [NB]. */
+int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
+                        float* logits_out, float* ws, int NB, int steps, void* stream);
+long long icap_greedy_tfm_ws_floats(int NB, int E, int FF, int V);
+
+typedef struct {
+    int E, H, V;                             /* embed dim, decoder dim, vocab */
+    const float* emb;                        /* [V][E] */
+    const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh; /* LSTMCell(E+enc -> H) */
+    const float* fc_w;                       /* [V][H] */
+    const float* fc_scale; const float* fc_bias; /* Linear bias and eval BatchNorm1d(V) folded */
+} icap_bah_weights;
+
+/* Greedy form of generate_caption for the Bahdanau model at one image per caption
+ * (TransformerTest_bahdnau.py:166-191 over transformer_word_level_bahdnau.py:127-141):
+ * with a single image the attention weight is 1 and the context is the encoder row.
+ * context [NB][ENC]. */
+int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
+                        long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream);
+long long icap_greedy_bah_ws_floats(int NB, int E, int ENC, int H, int V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICAP_HIP_H */

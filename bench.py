@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: greedy captioning throughput of the word-level transformer captioner
+(EfficientNet-B0 encoder + transformer encoder block + 20 greedy decoder steps) on synthetic
+224x224 images, one process per GPU.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of --batch images already resident in HBM:
+NCHW fp32 images -> encoder features -> 20 greedy tokens per image (every image decoded as its own
+batch of one, the reference's generate_caption semantics).  Inference shards by image: each rank
+captions its own images and no data-path collective exists, so scaling is weak.  Rank 0 prints ONE
+JSON line (metric, value, roofline of the dominant kernel, CPU baseline).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+VOCAB = 6756          # word vocabulary of the full dataset (notebook cell 5)
+CAPTION_LEN = 20      # greedy tokens per caption (BASELINE: 20-token titles)
+HBM_PEAK_GBS = 8000.0
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per step per GPU")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="images in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------- algorithmic work of one launch
+def conv_work(sig):
+    """(flops, bytes) of a conv2d launch from its trace signature: every input, weight and output element once."""
+    B, H, W, Cin, Cout, KH, stride, Ho, Wo, has_res, has_gate = sig
+    m = B * Ho * Wo
+    flops = 2.0 * m * Cout * KH * KH * Cin
+    byts = 4.0 * (B * H * W * Cin + Cout * KH * KH * Cin + m * Cout * (2 if has_res else 1))
+    return flops, byts
+
+
+def dw_work(sig):
+    B, H, W, Cc, ks, stride, Ho, Wo = sig
+    return 2.0 * B * Ho * Wo * Cc * ks * ks, 4.0 * (B * H * W * Cc + B * Ho * Wo * Cc)
+
+
+def linear_work(sig):
+    M, K, Nn, has_res = sig
+    return 2.0 * M * K * Nn, 4.0 * (M * K + K * Nn + M * Nn * (2 if has_res else 1))
+
+
+WORK = {"conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from image_captioning_amd import ops
+    from image_captioning_amd import transformer_word_level as twl
+    from image_captioning_amd.synthetic import seeded_state_dict, synthetic_images
+
+    model = twl.build_model(VOCAB)
+    model.load_state_dict(seeded_state_dict(model, seed=52))
+    model = model.eval().to(dev)
+    B = args.batch
+    # synthetic images: a small seeded pool tiled to the batch (content does not change the work)
+    pool = synthetic_images(min(B, 32), seed=1234 + rank)
+    images = pool.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
+
+    def step():
+        feats = model.cnn_model(images)
+        return model.greedy_ids_from_features(feats, CAPTION_LEN)
+
+    if args.breakdown:
+        breakdown(torch, ops, step, B)
+        return
+
+    # ---- dominant-kernel timing with events on the launch stream (torch's current stream) ----
+    dom_events = []
+    dom = {"name": None, "sig": None}
+
+    def find_dominant():
+        rec = []
+        ops.set_trace(lambda n, s: rec.append((n, s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))) or rec[-1][2:])
+        step()
+        torch.cuda.synchronize()
+        ops.set_trace(None)
+        agg = {}
+        for n, s, e0, e1 in rec:
+            agg[(n, s)] = agg.get((n, s), 0.0) + e0.elapsed_time(e1)
+        (n, s), _ = max(agg.items(), key=lambda kv: kv[1])
+        dom["name"], dom["sig"] = n, s
+
+    def dom_trace(n, s):
+        if n == dom["name"] and s == dom["sig"]:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            dom_events.append(ev)
+            return ev
+        return None
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    find_dominant()
+    ops.set_trace(dom_trace)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_trace(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert ids.shape == (B, CAPTION_LEN)
+
+    if rank == 0:
+        captions = world * B * args.steps
+        dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom_events) / max(len(dom_events), 1)
+        flops, byts = WORK[dom["name"]](dom["sig"])
+        hbm_t = byts / (HBM_PEAK_GBS * 1e9)
+        mfma_t = flops / (F32_MFMA_PEAK_TFLOPS * 1e12)
+        if hbm_t >= mfma_t:
+            roof = {"bound": "hbm", "achieved": byts / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        else:
+            roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["kernel"] = f"{dom['name']}{list(dom['sig'])}"
+        roof["avg_launch_ms"] = dom_ms
+        out = {
+            "metric": "captions/sec greedy + train imgs/sec, 224px food imgs, 1/2/4/8 MI355X",
+            "value": captions / elapsed, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "transformer_word_level: EfficientNet-B0 encoder + word-level transformer decoder, "
+                                   "batched greedy captioning (BASELINE configs[1])",
+                       "images_per_step_per_gpu": B, "image": "3x224x224 fp32", "caption_tokens": CAPTION_LEN, "vocab": VOCAB,
+                       "weights": "seeded random init", "parallelism": f"image-sharded x{world}, no collective"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(torch, model, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def breakdown(torch, ops, step, B):
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    rec = []
+    ops.set_trace(lambda n, s: rec.append((n, s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))) or rec[-1][2:])
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3
+    ops.set_trace(None)
+    rows, tot = [], 0.0
+    for n, s, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        fl, by = WORK[n](s)
+        rows.append((ms, n, s, fl / ms / 1e9, by / ms / 1e6))
+        tot += ms
+    print(f"step wall {wall:.3f} ms, traced launches {len(rec)} sum {tot:.3f} ms, batch {B}")
+    for ms, n, s, tf, gbs in rows:
+        print(f"{ms:9.4f} ms  {tf:8.2f} TFLOP/s {gbs:9.1f} GB/s  {n}{list(s)}")
+
+
+def cpu_baseline(torch, model, n):
+    """The CPU oracle on the host cores over a bounded sample: n synthetic images -> EfficientNet-B0 features
+    (once per image) -> 20 greedy steps per image with the reference's call pattern for the decoder (the model's
+    decoder side re-run on the growing prefix, one image at a time)."""
+    from image_captioning_amd.synthetic import synthetic_images
+    from oracle import backbones_ref as BR, torch_ref as R
+    sd = {k: (v.detach().cpu().float() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
+    imgs = synthetic_images(n, seed=99)
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        feats = torch.cat([BR.cnn_model(sd, imgs[i:i + 16]) for i in range(0, n, 16)])
+        for f in feats:
+            R.tfm_greedy(sd, f, 8, 8, CAPTION_LEN, 2, 3, False)
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "captions/s", "cores": threads, "kind": "port",
+            "sample": f"{n} synthetic 224x224 images: oracle EfficientNet-B0 (batches of 16) + per-image prefix-re-run greedy decode, "
+                      f"{CAPTION_LEN} tokens, fp32, torch CPU with {threads} threads, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

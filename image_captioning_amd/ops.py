@@ -19,6 +19,29 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional launch tracer for measurement harnesses: a callable (op_name, signature) -> None or a pair of
+# torch.cuda.Event that are recorded on the launch stream immediately before and after the kernel.
+_trace = None
+
+
+def set_trace(fn) -> None:
+    global _trace
+    _trace = fn
+
+
+class _Span:
+    __slots__ = ("ev",)
+
+    def __init__(self, name, sig):
+        self.ev = _trace(name, sig) if _trace is not None else None
+        if self.ev is not None:
+            self.ev[0].record()
+
+    def done(self):
+        if self.ev is not None:
+            self.ev[1].record()
+
+
 def _ck(t: torch.Tensor | None, name: str, dtype=torch.float32):
     if t is None:
         return None
@@ -64,9 +87,11 @@ def conv2d(x, w, scale=None, bias=None, residual=None, gate=None, *, stride=1, p
     for v, nm in ((scale, "scale"), (bias, "bias")):
         if v is not None and v.numel() != Cout:
             raise IcapError(f"conv2d: {nm} must have Cout={Cout} elements")
+    span = _Span("conv2d", (B, H, W, Cin, Cout, KH, stride, Ho, Wo, residual is not None, gate is not None))
     N.check(N.load().icap_conv2d_f32(
         _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"),
         _ck(gate, "gate"), _ck(out, "out"), B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo, act, _stream()), "conv2d")
+    span.done()
     return out
 
 
@@ -80,9 +105,11 @@ def linear(x, w, bias=None, scale=None, act=ACT_NONE, residual=None, out=None):
         out = torch.empty((M, Nn), device=x.device, dtype=torch.float32)
     if residual is not None and residual.numel() != M * Nn:
         raise IcapError("linear: residual has the wrong size")
+    span = _Span("linear", (M, K, Nn, residual is not None))
     N.check(N.load().icap_conv2d_f32(
         _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"), None,
         _ck(out, "out"), M, 1, 1, K, Nn, 1, 1, 1, 0, 0, 1, 1, act, _stream()), "linear")
+    span.done()
     return out
 
 
@@ -99,9 +126,11 @@ def dwconv2d(x, w, scale=None, bias=None, *, ks, stride=1, pad=(0, 0, 0, 0), act
     partial = None
     if want_partial:
         partial = torch.empty((B, lib.icap_dwconv_chunks(Ho, Wo), Cc), device=x.device, dtype=torch.float32)
+    span = _Span("dwconv2d", (B, H, W, Cc, ks, stride, Ho, Wo))
     N.check(lib.icap_dwconv2d_f32(_ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(y, "y"),
                                   _ck(partial, "partial"), B, H, W, Cc, ks, stride, pt, pl, Ho, Wo, act, _stream()),
             "dwconv2d")
+    span.done()
     return y, partial
 
 

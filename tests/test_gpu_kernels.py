@@ -1,0 +1,231 @@
+"""GPU: every C-ABI kernel against a plain fp32 torch CPU computation of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3   # fp32 tolerance of the hot path (features / logits)
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, want, rtol=RTOL, atol=1e-4, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, f"{what}: {tuple(got.shape)} vs {tuple(want.shape)}"
+    err = (got - want).abs() - (atol + rtol * want.abs())
+    assert err.max() <= 0, f"{what}: max abs diff {(got - want).abs().max():.3e} (max |want| {want.abs().max():.3e})"
+
+
+def act_ref(x, act):
+    from image_captioning_amd import ops
+    return {ops.ACT_NONE: lambda v: v, ops.ACT_RELU: torch.relu, ops.ACT_SWISH: lambda v: v * torch.sigmoid(v),
+            ops.ACT_SIGMOID: torch.sigmoid, ops.ACT_TANH: torch.tanh}[act](x)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, K, stride, pad(t,b,l,r), act, residual, gate
+    (2, 16, 16, 8, 32, 3, 1, (1, 1, 1, 1), 1, False, False),
+    (3, 17, 15, 16, 40, 3, 2, (0, 1, 0, 1), 2, False, False),       # TF-same asymmetric, odd sizes
+    (2, 23, 23, 4, 64, 7, 2, (3, 3, 3, 3), 1, False, False),        # resnet stem shape, padded 3->4 channels
+    (2, 14, 14, 24, 144, 1, 1, (0, 0, 0, 0), 2, False, False),      # K=24: tail of the 16-wide K slice masked
+    (2, 14, 14, 144, 24, 1, 1, (0, 0, 0, 0), 0, True, True),        # MBConv project: SE gate + skip
+    (2, 14, 14, 64, 128, 1, 2, (0, 0, 0, 0), 0, False, False),      # resnet downsample
+    (1, 56, 56, 64, 64, 3, 1, (1, 1, 1, 1), 1, True, False),        # basic block tail: residual then relu
+    (5, 9, 9, 32, 200, 3, 1, (1, 1, 1, 1), 0, False, False),        # Cout not a multiple of the tile
+    (40, 28, 28, 40, 96, 1, 1, (0, 0, 0, 0), 2, False, False),      # many rows, 128x128 tile path
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case):
+    from image_captioning_amd import ops
+    B, H, W, Cin, Cout, K, s, pad, act, use_res, use_gate = case
+    d = dev()
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, K, K, seed=2, scale=(Cin * K * K) ** -0.5)
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(3)) + 0.5
+    bias = rnd(Cout, seed=4, scale=0.1)
+    gate = torch.rand(B, Cin, generator=torch.Generator().manual_seed(5)) if use_gate else None
+    xin = x * gate[:, :, None, None] if use_gate else x
+    ref = F.conv2d(F.pad(xin, (pad[2], pad[3], pad[0], pad[1])), w, stride=s)
+    ref = ref * scale[None, :, None, None] + bias[None, :, None, None]
+    res = rnd(*ref.shape, seed=6) if use_res else None
+    if use_res:
+        ref = ref + res
+    ref = act_ref(ref, act)
+    y = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().to(d), w.permute(0, 2, 3, 1).contiguous().to(d), scale.to(d), bias.to(d),
+                   residual=res.permute(0, 2, 3, 1).contiguous().to(d) if use_res else None,
+                   gate=gate.to(d) if use_gate else None, stride=s, pad=pad, act=act)
+    close(y.permute(0, 3, 1, 2), ref, what=f"conv {case}")
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 512, 256), (8, 256, 512), (120, 512, 2048), (256, 2048, 512), (300, 512, 6756), (2000, 64, 97)])
+def test_linear(M, K, N):
+    from image_captioning_amd import ops
+    d = dev()
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    y = ops.linear(x.to(d), w.to(d), b.to(d), act=ops.ACT_RELU)
+    close(y, torch.relu(x @ w.t() + b), what=f"linear {M}x{K}x{N}")
+
+
+def test_nchw_to_nhwc_pad():
+    from image_captioning_amd import ops
+    x = rnd(3, 3, 10, 7, seed=1)
+    y = ops.nchw_to_nhwc_pad(x.to(dev()), 4).cpu()
+    assert torch.equal(y[..., :3], x.permute(0, 2, 3, 1))
+    assert torch.equal(y[..., 3], torch.zeros(3, 10, 7))
+
+
+@pytest.mark.parametrize("C,H,W,ks,s,pad", [(32, 20, 20, 3, 1, (1, 1, 1, 1)), (96, 21, 19, 3, 2, (0, 1, 0, 1)),
+                                             (144, 14, 14, 5, 2, (1, 2, 1, 2)), (240, 9, 9, 5, 1, (2, 2, 2, 2)),
+                                             (1152, 7, 7, 3, 1, (1, 1, 1, 1)), (672, 14, 14, 5, 1, (2, 2, 2, 2))])
+def test_dwconv_and_se(C, H, W, ks, s, pad):
+    from image_captioning_amd import ops
+    d = dev()
+    B = 3
+    x = rnd(B, C, H, W, seed=1)
+    w = rnd(C, 1, ks, ks, seed=2, scale=1.0 / ks)
+    scale = torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5
+    bias = rnd(C, seed=4, scale=0.1)
+    ref = F.conv2d(F.pad(x, (pad[2], pad[3], pad[0], pad[1])), w, stride=s, groups=C)
+    ref = ref * scale[None, :, None, None] + bias[None, :, None, None]
+    ref = ref * torch.sigmoid(ref)
+    y, part = ops.dwconv2d(x.permute(0, 2, 3, 1).contiguous().to(d), w.view(C, ks * ks).t().contiguous().to(d), scale.to(d),
+                           bias.to(d), ks=ks, stride=s, pad=pad, act=ops.ACT_SWISH, want_partial=True)
+    close(y.permute(0, 3, 1, 2), ref, what="dwconv")
+    hw = ref.shape[2] * ref.shape[3]
+    close(part.sum(1) / hw, ref.mean((2, 3)), what="dwconv partial pool")
+    S = max(1, C // 24)
+    wr, br, we, be = rnd(S, C, seed=5, scale=C ** -0.5), rnd(S, seed=6), rnd(C, S, seed=7, scale=S ** -0.5), rnd(C, seed=8)
+    gate = ops.se_gate(part, hw, wr.to(d), br.to(d), we.to(d), be.to(d))
+    sq = ref.mean((2, 3)) @ wr.t() + br
+    sq = sq * torch.sigmoid(sq)
+    close(gate, torch.sigmoid(sq @ we.t() + be), what="se gate")
+
+
+def test_pools():
+    from image_captioning_amd import ops
+    d = dev()
+    x = rnd(2, 64, 23, 23, seed=1)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(d)
+    close(ops.maxpool2d(xh, 3, 2, 1).permute(0, 3, 1, 2), F.max_pool2d(x, 3, 2, 1), what="maxpool 3/2/1")
+    close(ops.maxpool2d(xh, 2, 2, 0).permute(0, 3, 1, 2), F.max_pool2d(x, 2, 2), what="maxpool 2/2")
+    close(ops.adaptive_avgpool2d(xh, 1, 1).permute(0, 3, 1, 2), F.adaptive_avg_pool2d(x, 1), what="global avgpool")
+    close(ops.adaptive_avgpool2d(xh, 7, 7).permute(0, 3, 1, 2), F.adaptive_avg_pool2d(x, 7), what="adaptive 7x7")
+
+
+def test_embedding_layernorm_argmax():
+    from image_captioning_amd import ops
+    d = dev()
+    table, idx, add = rnd(97, 64, seed=1), torch.tensor([0, 5, 96, 5, 33]), rnd(5, 64, seed=2)
+    out, err = ops.embedding(table.to(d), idx.to(d), add.to(d))
+    assert torch.equal(out.cpu(), table[idx] + add) and int(err.item()) == 0
+    _, err = ops.embedding(table.to(d), torch.tensor([97]).to(d))
+    assert int(err.item()) == 1
+    x, res, g, b = rnd(11, 512, seed=3), rnd(11, 512, seed=4), rnd(512, seed=5), rnd(512, seed=6)
+    close(ops.layernorm(x.to(d), g.to(d), b.to(d), res=res.to(d)), F.layer_norm(x + res, (512,), g, b), what="layernorm")
+    close(ops.layernorm(x.to(d), g.to(d), b.to(d), res=x.to(d)), F.layer_norm(2 * x, (512,), g, b), what="layernorm 2x")
+    logits = rnd(9, 6756, seed=7)
+    logits[2, 100] = logits[2, 4000] = 50.0        # tie: the first index wins
+    logits[3, 6755] = 60.0
+    idx, gap = ops.argmax_rows(logits.to(d), want_gap=True)
+    assert idx.cpu().tolist() == logits.argmax(1).tolist() and idx[2].item() == 100
+    t2 = torch.topk(logits, 2, dim=1).values
+    close(gap, t2[:, 0] - t2[:, 1], what="top-2 gap")
+
+
+@pytest.mark.parametrize("Lq,Lk,N,Nk,E,heads", [(5, 5, 1, 1, 512, 8), (30, 3, 1, 1, 64, 4), (4, 6, 3, 3, 512, 2), (7, 12, 1, 1, 512, 4)])
+def test_mha_core(Lq, Lk, N, Nk, E, heads):
+    from image_captioning_amd import ops
+    d = dev()
+    q, k, v = rnd(Lq, N, E, seed=1), rnd(Lk, Nk, E, seed=2), rnd(Lk, Nk, E, seed=3)
+    hd = E // heads
+    kk, vv = k.expand(Lk, N, E), v.expand(Lk, N, E)
+    Q = q.reshape(Lq, N * heads, hd).transpose(0, 1) / hd ** 0.5
+    K = kk.reshape(Lk, N * heads, hd).transpose(0, 1)
+    V = vv.reshape(Lk, N * heads, hd).transpose(0, 1)
+    ref = (torch.softmax(Q @ K.transpose(1, 2), -1) @ V).transpose(0, 1).reshape(Lq, N, E)
+    close(ops.mha_core(q.to(d), k.to(d), v.to(d), heads), ref, what="mha core")
+
+
+@pytest.mark.parametrize("B", [1, 5, 64])
+def test_bahdanau_attention(B):
+    from image_captioning_amd import ops
+    d = dev()
+    A, E = 256, 512
+    u, w, aw, feat = rnd(B, A, seed=1), rnd(B, A, seed=2), rnd(A, seed=3, scale=A ** -0.5), rnd(B, E, seed=4)
+    scores = (torch.tanh(u[None, :, :] + w[:, None, :]) * aw).sum(-1) + 0.3
+    alpha = torch.softmax(scores, 1)
+    a, c = ops.bahdanau_attention(u.to(d), w.to(d), aw.to(d), 0.3, feat.to(d))
+    close(a, alpha, what="alpha")
+    close(c, alpha @ feat, what="context")
+
+
+def test_pointwise_cells():
+    from image_captioning_amd import ops
+    from oracle import torch_ref as R
+    d = dev()
+    B, H, I = 5, 64, 32
+    w_ih, w_hh, b_ih, b_hh = rnd(4 * H, I, seed=1, scale=0.2), rnd(4 * H, H, seed=2, scale=0.2), rnd(4 * H, seed=3), rnd(4 * H, seed=4)
+    x, h, c = rnd(B, I, seed=5), rnd(B, H, seed=6), rnd(B, H, seed=7)
+    gates = x @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+    h2, c2 = ops.lstm_pointwise(gates.to(d), c.to(d))
+    rh, rc = R.lstm_cell(w_ih, w_hh, b_ih, b_hh, x, h, c)
+    close(h2, rh, what="lstm h"); close(c2, rc, what="lstm c")
+    g_ih, g_hh = w_ih[:3 * H], w_hh[:3 * H]
+    gi, gh = x @ g_ih.t() + b_ih[:3 * H], h @ g_hh.t() + b_hh[:3 * H]
+    close(ops.gru_pointwise(gi.to(d), gh.to(d), h.to(d)), R.gru_cell(g_ih, g_hh, b_ih[:3 * H], b_hh[:3 * H], x, h), what="gru h")
+
+
+@pytest.mark.parametrize("NB", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("N,K", [(6756, 512), (512, 2048), (81, 512), (2048, 512)])
+def test_gemv(NB, N, K):
+    from image_captioning_amd import ops
+    d = dev()
+    W, b, x = rnd(N, K, seed=1, scale=K ** -0.5), rnd(N, seed=2), rnd(NB, K, seed=3)
+    ref = x @ W.t() + b
+    y, pv, pi = ops.gemv(W.to(d), x.to(d), b.to(d), want_partials=True)
+    close(y, ref, what="gemv")
+    best = pv.cpu().max(1)
+    got_idx = pi.cpu().gather(1, best.indices[:, None])[:, 0]
+    assert got_idx.tolist() == ref.argmax(1).tolist()
+    close(ops.gemv(W.to(d), x.to(d), b.to(d), act=ops.ACT_RELU), torch.relu(ref), what="gemv relu")
+
+
+@pytest.mark.parametrize("NB", [1, 4, 8])
+@pytest.mark.parametrize("I,H", [(512, 512), (1024, 512), (32, 64)])
+def test_fused_cells(NB, I, H):
+    from image_captioning_amd import ops
+    from oracle import torch_ref as R
+    d = dev()
+    w_ih, w_hh = rnd(4 * H, I, seed=1, scale=I ** -0.5), rnd(4 * H, H, seed=2, scale=H ** -0.5)
+    b_ih, b_hh = rnd(4 * H, seed=3, scale=0.1), rnd(4 * H, seed=4, scale=0.1)
+    x, h, c = rnd(NB, I, seed=5), rnd(NB, H, seed=6, scale=0.5), rnd(NB, H, seed=7, scale=0.5)
+    h2, c2 = ops.lstm_cell(w_ih.to(d), w_hh.to(d), b_ih.to(d), b_hh.to(d), x.to(d), h.to(d), c.to(d))
+    rh, rc = R.lstm_cell(w_ih, w_hh, b_ih, b_hh, x, h, c)
+    close(h2, rh, what="lstm_cell h"); close(c2, rc, what="lstm_cell c")
+    g = slice(0, 3 * H)
+    h3 = ops.gru_cell(w_ih[g].contiguous().to(d), w_hh[g].contiguous().to(d), b_ih[g].contiguous().to(d),
+                      b_hh[g].contiguous().to(d), x.to(d), h.to(d))
+    close(h3, R.gru_cell(w_ih[g], w_hh[g], b_ih[g], b_hh[g], x, h), what="gru_cell h")
+
+
+def test_argument_errors_are_raised():
+    from image_captioning_amd import ops
+    d = dev()
+    with pytest.raises(ops.IcapError):
+        ops.linear(torch.zeros(4, 8), torch.zeros(3, 8))                       # CPU tensors: no fallback
+    with pytest.raises(ops.IcapError):
+        ops.conv2d(torch.zeros(1, 4, 4, 6, device=d), torch.zeros(8, 1, 1, 6, device=d))   # Cin % 4
+    with pytest.raises(ops.IcapError):
+        ops.gemv(torch.zeros(16, 8, device=d), torch.zeros(9, 8, device=d))    # more than 8 lock-step rows

@@ -57,7 +57,7 @@ SIGNATURES = {
     "icap_nchw_to_nhwc_pad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "icap_conv2d_f32": (_i, [_p] * 7 + [_i] * 13 + [_p]),
     "icap_dwconv2d_f32": (_i, [_p] * 6 + [_i] * 11 + [_p]),
-    "icap_dwconv_chunks": (_i, [_i, _i]),
+    "icap_dwconv_chunks": (_i, [_i, _i, _i]),
     "icap_se_gate_f32": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "icap_maxpool2d_f32": (_i, [_p, _p] + [_i] * 9 + [_p]),
     "icap_adaptive_avgpool2d_f32": (_i, [_p, _p] + [_i] * 6 + [_p]),

@@ -42,90 +42,114 @@ int nchw_to_nhwc_pad_f32(const float* src, float* dst, int B, int C, int H, int 
 }
 
 // ---------------------------------------------------------------- depthwise conv
-// One workgroup covers a chunk of P output pixels of one image for all channels.
-// Thread (tx, py): channel quad tx, pixel lane py.  The per-channel sums over the
-// chunk (needed by squeeze-excite) are reduced across pixel lanes in a fixed order
-// and written to partial[b][chunk][C]; the gate kernel adds the chunks in order, so
-// the pooled value does not depend on scheduling.
-template <int KS>
-__global__ __launch_bounds__(256) void dwconv_kernel(
+// Register-strip kernel: a thread owns one channel quad (16 B of the NHWC channel axis) and a strip of TW
+// consecutive output pixels of one output row.  For every filter row it walks the input row once, each
+// loaded float4 feeding all outputs whose window covers it, so a strip costs ((TW-1)*S+KS)*KS loads instead
+// of TW*KS*KS; rows shared by vertically adjacent strips come from L1/L2.  Threads are laid out with the
+// channel quad fastest (coalesced 16-B lanes) and a workgroup covers `spb` whole strips of one image.
+// The per-channel sums of the workgroup's outputs (needed by squeeze-excite) are reduced through LDS in a
+// fixed order and written to partial[b][workgroup][C]; the gate kernel adds the workgroups in order, so the
+// pooled value does not depend on scheduling.
+constexpr int DW_TW = 7;   // divides every EfficientNet-B0 feature-map width (112, 56, 28, 14, 7)
+
+template <int KS, int S>
+__global__ __launch_bounds__(512) void dwconv_strip_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
     const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ partial, int H, int W,
-    int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, int P, int nqp_log2) {
-    __shared__ float4 red[256];
+    int C, int pad_t, int pad_l, int Ho, int Wo, int act, int nq, int spb, int nstrips_w) {
+    extern __shared__ __attribute__((aligned(16))) float4 red[];
+    constexpr int TW = DW_TW;
+    constexpr int NIN = (TW - 1) * S + KS;
     const int tid = threadIdx.x;
-    const int nq = C >> 2;
-    const int NQP = 1 << nqp_log2;
-    const int PL = 256 >> nqp_log2;
-    const int tx = tid & (NQP - 1);
-    const int py = tid >> nqp_log2;
     const int b = blockIdx.y;
-    const int chunk = blockIdx.x;
-    const int nchunks = gridDim.x;
-    const int HoWo = Ho * Wo;
-    const int pix_begin = chunk * P;
-    const int pix_end = min(pix_begin + P, HoWo);
-    const float* xb = x + (size_t)b * H * W * C;
-    float* yb = y + (size_t)b * HoWo * C;
-    float* pb = partial ? partial + ((size_t)b * nchunks + chunk) * C : nullptr;
-
-    for (int cq = tx; cq < nq; cq += NQP) {
+    const int ls = tid / nq;
+    const int cq = tid - ls * nq;
+    const int strip = blockIdx.x * spb + ls;
+    const int nstrips = Ho * nstrips_w;
+    const bool active = (ls < spb) && (strip < nstrips);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
         const int c = cq << 2;
-        const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 bi = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 wreg[KS * KS];
+        const int ho = strip / nstrips_w;
+        const int wo0 = (strip - ho * nstrips_w) * TW;
+        const int hi0 = ho * S - pad_t, wi0 = wo0 * S - pad_l;
+        const float* xb = x + (size_t)b * H * W * C + c;
+        float4 acc[TW];
 #pragma unroll
-        for (int t = 0; t < KS * KS; ++t) wreg[t] = *reinterpret_cast<const float4*>(w + (size_t)t * C + c);
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pix = pix_begin + py; pix < pix_end; pix += PL) {
-            const int ho = pix / Wo, wo = pix - ho * Wo;
-            const int hi0 = ho * stride - pad_t, wi0 = wo * stride - pad_l;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int o = 0; o < TW; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int r = 0; r < KS; ++r) {
-                const int hi = hi0 + r;
-                if ((unsigned)hi >= (unsigned)H) continue;
+        for (int r = 0; r < KS; ++r) {
+            const int hi = hi0 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            float4 wr[KS];
 #pragma unroll
-                for (int q = 0; q < KS; ++q) {
-                    const int wi = wi0 + q;
-                    if ((unsigned)wi >= (unsigned)W) continue;
-                    const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)hi * W + wi) * C + c);
-                    const float4 k = wreg[r * KS + q];
-                    a.x = fmaf(v.x, k.x, a.x); a.y = fmaf(v.y, k.y, a.y);
-                    a.z = fmaf(v.z, k.z, a.z); a.w = fmaf(v.w, k.w, a.w);
+            for (int q = 0; q < KS; ++q) wr[q] = *reinterpret_cast<const float4*>(w + (size_t)(r * KS + q) * C + c);
+            const float* xr = xb + (size_t)hi * W * C;
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                const int wi = wi0 + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)wi < (unsigned)W) v = *reinterpret_cast<const float4*>(xr + (size_t)wi * C);
+#pragma unroll
+                for (int o = 0; o < TW; ++o) {
+                    const int q = j - o * S;
+                    if (q >= 0 && q < KS) {
+                        acc[o].x = fmaf(v.x, wr[q].x, acc[o].x); acc[o].y = fmaf(v.y, wr[q].y, acc[o].y);
+                        acc[o].z = fmaf(v.z, wr[q].z, acc[o].z); acc[o].w = fmaf(v.w, wr[q].w, acc[o].w);
+                    }
                 }
             }
-            float4 o;
-            o.x = act_apply(fmaf(a.x, sc.x, bi.x), act); o.y = act_apply(fmaf(a.y, sc.y, bi.y), act);
-            o.z = act_apply(fmaf(a.z, sc.z, bi.z), act); o.w = act_apply(fmaf(a.w, sc.w, bi.w), act);
-            *reinterpret_cast<float4*>(yb + (size_t)pix * C + c) = o;
-            sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
         }
-        if (PL == 1) {
-            if (pb) *reinterpret_cast<float4*>(pb + c) = sum;
-        } else {
-            red[tid] = sum;  // with PL > 1 every thread runs this loop body at most once
+        const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 bi = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* yr = y + ((size_t)b * Ho * Wo + (size_t)ho * Wo) * C + c;
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            const int wo = wo0 + o;
+            if (wo < Wo) {
+                float4 v;
+                v.x = act_apply(fmaf(acc[o].x, sc.x, bi.x), act); v.y = act_apply(fmaf(acc[o].y, sc.y, bi.y), act);
+                v.z = act_apply(fmaf(acc[o].z, sc.z, bi.z), act); v.w = act_apply(fmaf(acc[o].w, sc.w, bi.w), act);
+                *reinterpret_cast<float4*>(yr + (size_t)wo * C) = v;
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
         }
     }
-    if (PL > 1 && pb) {
+    if (partial) {
+        red[tid] = sum;
         __syncthreads();
-        if (py == 0 && tx < nq) {
-            float4 s = red[tx];
-            for (int l = 1; l < PL; ++l) {
-                const float4 o = red[(l << nqp_log2) + tx];
-                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        if (tid < nq) {
+            float4 t = red[tid];
+            for (int l = 1; l < spb; ++l) {
+                const float4 o = red[l * nq + tid];
+                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
             }
-            *reinterpret_cast<float4*>(pb + (tx << 2)) = s;
+            *reinterpret_cast<float4*>(partial + ((size_t)b * gridDim.x + blockIdx.x) * C + (tid << 2)) = t;
         }
     }
 }
 
-int dwconv_chunks(int Ho, int Wo, int* P_out) {
-    // 64 output pixels per workgroup keeps >1k workgroups in flight on the large
-    // early layers and a single chunk on the 7x7 tail.
-    const int P = 64;
-    if (P_out) *P_out = P;
-    return (Ho * Wo + P - 1) / P;
+// Launch geometry shared by the kernel launcher and by callers sizing the partial buffer.
+static void dwconv_geometry(int Ho, int Wo, int C, int* block, int* spb, int* nblk) {
+    const int nq = C / 4;
+    int best_bd = 0, best_spb = 1;
+    double best_u = -1.0;
+    for (int bd = 128; bd <= 512; bd += 64) {
+        if (bd < nq) continue;
+        const int s = bd / nq;
+        const double u = (double)(s * nq) / bd;
+        if (u > best_u + 1e-9) { best_u = u; best_bd = bd; best_spb = s; }
+    }
+    const int nstrips = Ho * ((Wo + DW_TW - 1) / DW_TW);
+    if (best_spb > nstrips) best_spb = nstrips;
+    *block = best_bd; *spb = best_spb; *nblk = (nstrips + best_spb - 1) / best_spb;
+}
+
+int dwconv_chunks(int Ho, int Wo, int C) {
+    if (Ho <= 0 || Wo <= 0 || C <= 0 || C % 4 || C / 4 > 512) return -1;
+    int bd, spb, nblk;
+    dwconv_geometry(Ho, Wo, C, &bd, &spb, &nblk);
+    return nblk;
 }
 
 int dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y,
@@ -136,23 +160,25 @@ int dwconv2d_f32(const float* x, const float* w, const float* scale, const float
         return ICAP_ERR_ARG;
     }
     if (C % 4) { set_error("dwconv2d: C=%d must be a multiple of 4", C); return ICAP_ERR_ALIGN; }
+    if (C / 4 > 512) { set_error("dwconv2d: C=%d exceeds 2048", C); return ICAP_ERR_LIMIT; }
     if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (partial && !aligned16(partial)) ||
         (scale && !aligned16(scale)) || (bias && !aligned16(bias))) {
         set_error("dwconv2d: pointers must be 16-byte aligned");
         return ICAP_ERR_ALIGN;
     }
     if (B > 65535) { set_error("dwconv2d: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
-    int P;
-    const int nchunks = dwconv_chunks(Ho, Wo, &P);
-    const int nq = C / 4;
-    int lg = 0;
-    while ((1 << lg) < nq && lg < 8) ++lg;
-    dim3 grid(nchunks, B), block(256);
-    if (KS == 3)
-        hipLaunchKernelGGL(dwconv_kernel<3>, grid, block, 0, st, x, w, scale, bias, y, partial, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, P, lg);
-    else if (KS == 5)
-        hipLaunchKernelGGL(dwconv_kernel<5>, grid, block, 0, st, x, w, scale, bias, y, partial, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, P, lg);
-    else { set_error("dwconv2d: kernel size %d not supported (3 or 5)", KS); return ICAP_ERR_ARG; }
+    int bd, spb, nblk;
+    dwconv_geometry(Ho, Wo, C, &bd, &spb, &nblk);
+    const int nq = C / 4, nsw = (Wo + DW_TW - 1) / DW_TW;
+    const dim3 grid(nblk, B), block(bd);
+    const size_t lds = partial ? (size_t)bd * sizeof(float4) : 0;
+#define ICAP_DW(K_, S_) hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_>), grid, block, lds, st, x, w, scale, bias, y, partial, H, W, C, pad_t, pad_l, Ho, Wo, act, nq, spb, nsw)
+    if (KS == 3 && stride == 1) ICAP_DW(3, 1);
+    else if (KS == 3 && stride == 2) ICAP_DW(3, 2);
+    else if (KS == 5 && stride == 1) ICAP_DW(5, 1);
+    else if (KS == 5 && stride == 2) ICAP_DW(5, 2);
+    else { set_error("dwconv2d: kernel %d stride %d not supported (3 or 5, stride 1 or 2)", KS, stride); return ICAP_ERR_ARG; }
+#undef ICAP_DW
     return launch_status("dwconv2d");
 }
 

@@ -11,10 +11,18 @@
 // A while it is staged, which is how the squeeze-excite scale of an MBConv block
 // is applied without a separate pass over the expanded tensor.
 //
-// Tiling: BM x BN outputs per 256-thread workgroup (4 waves), BK = 16.  Each wave
-// owns a (BM/WM) x (BN/WN) sub-tile built from 32x32 MFMA blocks.  Operand tiles
-// are staged global -> registers -> LDS (double buffered, one barrier per K step)
-// with 80-byte LDS rows so that the ds_read_b128 fragment reads are conflict free.
+// Tiling: BM x BN outputs per 256-thread workgroup (4 waves).  The waves are
+// arranged WM x WN over the tile and KSPLIT over the K slice (WM*WN*KSPLIT = 4):
+// big problems use 2x2 or 4x1 waves on one 16-wide K slice, problems with only a
+// few hundred rows (decode-time linears) use a 32x32 tile with the four waves
+// splitting a 64-wide K slice and a fixed-order reduction through LDS, so that
+// even [256 x 512] outputs put >100 workgroups on the chip.
+// Operand tiles are staged global -> registers -> LDS (double buffered, one
+// barrier per K step); LDS rows are padded by 16 B so ds_read_b128 fragment
+// reads are conflict free.  The epilogue transposes the accumulators through LDS
+// and writes 16 B per lane along the channel axis (full 128-B lines per row).
+// Workgroup ids are remapped so that tiles sharing activation rows land on the
+// same XCD (its L2 then serves the re-reads).
 #include "common.hpp"
 
 namespace icap {
@@ -31,42 +39,63 @@ struct ConvParams {
     float* y;
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act;
     int M, K, ldy;
-    int tiles_n;
+    int tiles_n, nblk, vec_ok;
 };
 
-constexpr int BK = 16;
-constexpr int LDK = 20;  // padded LDS row (floats): 80 B keeps 16-B alignment, spreads banks
+constexpr int BK = 16;       // K elements one wave consumes per step
+constexpr int EP_ROWS = 64;  // output rows per epilogue pass
 
-template <int BM, int BN, int WM, int WN, bool ONE_BY_ONE>
+template <int BM, int BN, int WM, int WN, int KSPLIT, bool ONE_BY_ONE, bool GATE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int RM = TM / 32, RN = TN / 32;
-    constexpr int RA = (BM * 4 + 255) / 256;  // float4 chunks of A per thread
-    constexpr int RB = (BN * 4 + 255) / 256;
-    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int CPR = 4 * KSPLIT;           // float4 chunks per staged row
+    constexpr int BKS = BK * KSPLIT;          // K elements staged per step
+    constexpr int LDK = BKS + 4;              // padded LDS row (floats)
+    constexpr int RPI = 256 / CPR;            // rows staged per pass of the 256 threads
+    constexpr int RA = (BM + RPI - 1) / RPI;
+    constexpr int RB = (BN + RPI - 1) / RPI;
+    constexpr int EP_LD = BN + 4;
+    constexpr int EP_R = BM < EP_ROWS ? BM : EP_ROWS;
+    constexpr int STAGE_FLOATS = 2 * (BM + BN) * LDK;
+    constexpr int EP_FLOATS = KSPLIT * EP_R * EP_LD;
+    constexpr int SMEM_FLOATS = STAGE_FLOATS > EP_FLOATS ? STAGE_FLOATS : EP_FLOATS;
+    static_assert(WM * WN * KSPLIT == 4, "four waves per workgroup");
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is built from 32x32 blocks");
+    static_assert(KSPLIT == 1 || (WM == 1 && WN == 1), "K split uses one output tile per workgroup");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    float* As = smem;                       // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;        // [2][BN][LDK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int ks = KSPLIT > 1 ? wave : 0;
+    const int wm = KSPLIT > 1 ? 0 : wave / WN;
+    const int wn = KSPLIT > 1 ? 0 : wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
 
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const int tile_m = blockIdx.x / p.tiles_n;
+    // XCD-aware tile order: workgroups b and b+8 share an XCD, so give each of the 8 groups a
+    // contiguous range of tiles (n fastest): tiles that re-read the same activation rows share an L2.
+    int logical;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = logical % p.tiles_n;
+    const int tile_m = logical / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-thread staging coordinates (fixed over the K loop) ----
-    const int kc = tid & 3;  // which float4 of the 16-wide K slice
+    const int kcx = tid % CPR;   // which float4 of the staged K slice
+    const int srow = tid / CPR;
     const float* a_base[RA];
     int a_hi0[RA], a_wi0[RA], a_b[RA];
     bool a_ok[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int row = (tid >> 2) + 64 * i;
+        const int row = srow + RPI * i;
         const int m = m0 + row;
         a_ok[i] = (row < BM) && (m < p.M);
         const int mm = a_ok[i] ? m : 0;
@@ -84,16 +113,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     bool b_ok[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int row = (tid >> 2) + 64 * i;
+        const int row = srow + RPI * i;
         const int n = n0 + row;
         b_ok[i] = (row < BN) && (n < p.Cout);
         b_base[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K;
     }
 
-    float4 ra[RA], rb[RB];
+    // Staging registers for the tile in flight.  Every load below is unconditional (out-of-range
+    // elements read a valid dummy address and are zeroed when the tile is written to LDS) and nothing
+    // consumes a loaded value before lds_store(), so the loads of tile t+1 stay in flight behind the
+    // MFMAs of tile t instead of being waited for where they are issued.
+    float4 ra[RA], rb[RB], rg[GATE ? RA : 1];
+    unsigned okmask = 0;   // bit i: ra[i] valid, bit 16+i: rb[i] valid
 
     auto gload = [&](int t) {
-        const int kk = t * BK + kc * 4;
+        const int kk = t * BKS + kcx * 4;
         const bool kin = kk < p.K;
         int r = 0, q = 0, c = kk;
         if (!ONE_BY_ONE) {
@@ -102,36 +136,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             r = tap / p.KW;
             q = tap - r * p.KW;
         }
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int hi = a_hi0[i] + r, wi = a_wi0[i] + q;
-            if (kin && a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-                v = *reinterpret_cast<const float4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + c);
-                if (p.gate) {
-                    const float4 g = *reinterpret_cast<const float4*>(p.gate + (size_t)a_b[i] * p.Cin + c);
-                    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
-                }
-            }
-            ra[i] = v;
+            const bool ok = kin && a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float* src = ok ? a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + c : p.x;
+            ra[i] = *reinterpret_cast<const float4*>(src);
+            if (GATE) rg[i] = *reinterpret_cast<const float4*>(ok ? p.gate + (size_t)a_b[i] * p.Cin + c : p.gate);
+            okmask |= ok ? (1u << i) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kin && b_ok[i]) v = *reinterpret_cast<const float4*>(b_base[i] + kk);
-            rb[i] = v;
+            const bool ok = kin && b_ok[i];
+            rb[i] = *reinterpret_cast<const float4*>(ok ? b_base[i] + kk : p.w);
+            okmask |= ok ? (1u << (16 + i)) : 0u;
         }
     };
     auto lds_store = [&](int buf) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int row = (tid >> 2) + 64 * i;
-            if (row < BM) *reinterpret_cast<float4*>(&As[buf][row][kc * 4]) = ra[i];
+            const int row = srow + RPI * i;
+            float4 v = ra[i];
+            if (GATE) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+            if (!((okmask >> i) & 1u)) v = z;
+            if (row < BM) *reinterpret_cast<float4*>(&As[(buf * BM + row) * LDK + kcx * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int row = (tid >> 2) + 64 * i;
-            if (row < BN) *reinterpret_cast<float4*>(&Bs[buf][row][kc * 4]) = rb[i];
+            const int row = srow + RPI * i;
+            const float4 v = ((okmask >> (16 + i)) & 1u) ? rb[i] : z;
+            if (row < BN) *reinterpret_cast<float4*>(&Bs[(buf * BN + row) * LDK + kcx * 4]) = v;
         }
     };
 
@@ -143,7 +179,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (p.K + BKS - 1) / BKS;
     gload(0);
     lds_store(0);
     __syncthreads();
@@ -153,12 +189,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const bool more = (t + 1) < nk;
         if (more) gload(t + 1);
 
-        // Lane (lr, lh) owns k = 8*lh + s of this slice for MFMA step s: any
+        // Lane (lr, lh) owns k = 8*lh + s of its wave's 16-wide slice for MFMA step s: any
         // k -> (step, half) assignment is valid as long as A and B agree.
         float af[RM][8], bf[RN][8];
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
-            const float* src = &As[cur][wm * TM + i * 32 + lr][8 * lh];
+            const float* src = &As[(cur * BM + wm * TM + i * 32 + lr) * LDK + ks * BK + 8 * lh];
             const float4 v0 = *reinterpret_cast<const float4*>(src);
             const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
             af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
@@ -166,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
-            const float* src = &Bs[cur][wn * TN + j * 32 + lr][8 * lh];
+            const float* src = &Bs[(cur * BN + wn * TN + j * 32 + lr) * LDK + ks * BK + 8 * lh];
             const float4 v0 = *reinterpret_cast<const float4*>(src);
             const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
             bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
@@ -185,30 +221,79 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         cur ^= 1;
     }
 
-    // ---- epilogue: lane holds column n = lr, rows (e&3) + 8*(e>>2) + 4*lh ----
+    // ---- epilogue: accumulators -> LDS (row-major tile) -> 16-B channel-contiguous stores ----
+    // A lane holds column n = lr and rows (e&3) + 8*(e>>2) + 4*lh of each 32x32 block.
+    float* ep = smem;  // [KSPLIT][EP_R][EP_LD]; the staging buffers are dead after the last barrier
+    constexpr int BN4 = BN / 4;
+    constexpr int EP_RPI = 256 / BN4;
+    const int en4 = tid % BN4, erow = tid / BN4;
+    const int n = n0 + en4 * 4;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.vec_ok) {
+        if (n < p.Cout) {
+            if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
+            if (p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + n);
+        }
+    } else {
+        float* s = reinterpret_cast<float*>(&sc4);
+        float* bb = reinterpret_cast<float*>(&bi4);
+        for (int u = 0; u < 4; ++u)
+            if (n + u < p.Cout) {
+                if (p.scale) s[u] = p.scale[n + u];
+                if (p.bias) bb[u] = p.bias[n + u];
+            }
+    }
+    constexpr int NPASS = (BM + EP_ROWS - 1) / EP_ROWS;
 #pragma unroll
-    for (int j = 0; j < RN; ++j) {
-        const int n = n0 + wn * TN + j * 32 + lr;
-        if (n >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float bi = p.bias ? p.bias[n] : 0.f;
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int r0 = pass * EP_ROWS;
+        if (wm * TM >= r0 && wm * TM < r0 + EP_ROWS) {
 #pragma unroll
-        for (int i = 0; i < RM; ++i) {
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.M) {
-                    float v = fmaf(acc[i][j][e], sc, bi);
-                    const size_t o = (size_t)m * p.ldy + n;
-                    if (p.residual) v += p.residual[o];
-                    p.y[o] = act_apply(v, p.act);
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh - r0;
+                        ep[(ks * EP_R + row) * EP_LD + wn * TN + j * 32 + lr] = acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+        for (int row = erow; row < EP_R; row += EP_RPI) {
+            const int m = m0 + r0 + row;
+            if (m >= p.M || n >= p.Cout) continue;
+            float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
+#pragma unroll
+            for (int k2 = 1; k2 < KSPLIT; ++k2) {
+                const float4 o = *reinterpret_cast<const float4*>(&ep[(k2 * EP_R + row) * EP_LD + en4 * 4]);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
+            v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
+            const size_t o = (size_t)m * p.ldy + n;
+            if (p.vec_ok) {
+                if (p.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + o);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
+                v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act);
+                v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
+                *reinterpret_cast<float4*>(p.y + o) = v;
+            } else {
+                const float* vv = reinterpret_cast<const float*>(&v);
+                for (int u = 0; u < 4; ++u)
+                    if (n + u < p.Cout) {
+                        float t = vv[u];
+                        if (p.residual) t += p.residual[o + u];
+                        p.y[o + u] = act_apply(t, p.act);
+                    }
             }
         }
+        if (pass + 1 < NPASS) __syncthreads();
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KSPLIT>
 static int launch_cfg(ConvParams& p, hipStream_t st) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
@@ -217,11 +302,17 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
         set_error("conv_igemm: grid of %lld workgroups out of range", blocks);
         return ICAP_ERR_LIMIT;
     }
+    p.nblk = (int)blocks;
     const bool one = (p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0);
-    if (one)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)blocks), block(256);
+    if (one && p.gate)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, true, true>), grid, block, 0, st, p);
+    else if (one)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, true, false>), grid, block, 0, st, p);
+    else if (p.gate)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, false, true>), grid, block, 0, st, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, false, false>), grid, block, 0, st, p);
     return launch_status("conv_igemm");
 }
 
@@ -252,17 +343,20 @@ int conv_igemm_f32(const float* x, const float* w, const float* scale, const flo
         return ICAP_ERR_LIMIT;
     }
     ConvParams p{x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW,
-                 stride, pad_t, pad_l, Ho, Wo, act, (int)M, (int)K, Cout, 0};
-    // Tile choice: wide N tiles when there are channels to fill them, tall M tiles
-    // for thin layers, and small tiles when the whole problem is only a few
-    // hundred rows (decode-time linears) so that the grid still covers the chip.
+                 stride, pad_t, pad_l, Ho, Wo, act, (int)M, (int)K, Cout, 0, 0, 0};
+    p.vec_ok = (Cout % 4 == 0) && aligned16(y) && (!residual || aligned16(residual)) &&
+               (!scale || aligned16(scale)) && (!bias || aligned16(bias));
+    // Tile choice: wide N tiles when there are channels to fill them, tall M tiles for thin layers, and
+    // for problems of only a few hundred rows a 32x32 tile whose four waves split K.
+    const long long tiles128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+    if (tiles128 < 256 && K >= 128) return launch_cfg<32, 32, 1, 1, 4>(p, st);
     if (M <= 1024) {
-        if (Cout <= 32) return launch_cfg<128, 32, 4, 1>(p, st);
-        return launch_cfg<64, 64, 2, 2>(p, st);
+        if (Cout <= 32) return launch_cfg<128, 32, 4, 1, 1>(p, st);
+        return launch_cfg<64, 64, 2, 2, 1>(p, st);
     }
-    if (Cout <= 32) return launch_cfg<256, 32, 4, 1>(p, st);
-    if (Cout <= 64) return launch_cfg<256, 64, 4, 1>(p, st);
-    return launch_cfg<128, 128, 2, 2>(p, st);
+    if (Cout <= 32) return launch_cfg<256, 32, 4, 1, 1>(p, st);
+    if (Cout <= 64) return launch_cfg<256, 64, 4, 1, 1>(p, st);
+    return launch_cfg<128, 128, 2, 2, 1>(p, st);
 }
 
 }  // namespace icap

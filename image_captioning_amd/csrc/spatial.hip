@@ -80,7 +80,8 @@ __global__ __launch_bounds__(512) void dwconv_strip_kernel(
 #pragma unroll
         for (int r = 0; r < KS; ++r) {
             const int hi = hi0 + r;
-            if ((unsigned)hi >= (unsigned)H) continue;
+            const bool row_ok = (unsigned)hi < (unsigned)H;   // wave-divergent only at image borders
+            if (!row_ok) continue;
             float4 wr[KS];
 #pragma unroll
             for (int q = 0; q < KS; ++q) wr[q] = *reinterpret_cast<const float4*>(w + (size_t)(r * KS + q) * C + c);
@@ -88,8 +89,9 @@ __global__ __launch_bounds__(512) void dwconv_strip_kernel(
 #pragma unroll
             for (int j = 0; j < NIN; ++j) {
                 const int wi = wi0 + j;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((unsigned)wi < (unsigned)W) v = *reinterpret_cast<const float4*>(xr + (size_t)wi * C);
+                const bool ok = (unsigned)wi < (unsigned)W;
+                float4 v = *reinterpret_cast<const float4*>(ok ? xr + (size_t)wi * C : xr);   // always a valid address
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int o = 0; o < TW; ++o) {
                     const int q = j - o * S;

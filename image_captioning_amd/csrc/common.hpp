@@ -48,6 +48,33 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
+// Compile-time activation: kernels dispatch on the runtime code ONCE per tile / thread and run a
+// straight-line epilogue; a per-element runtime switch costs a scalar branch tree per value and keeps
+// the compiler from forming 16-byte stores.
+template <int ACT>
+__device__ __forceinline__ float act_c(float v) {
+    if constexpr (ACT == ACT_RELU) return fmaxf(v, 0.f);
+    else if constexpr (ACT == ACT_SWISH) return v * sigmoid_fast(v);
+    else if constexpr (ACT == ACT_SIGMOID) return sigmoid_fast(v);
+    else if constexpr (ACT == ACT_TANH) return tanhf(v);
+    else return v;
+}
+
+template <int ACT>
+struct ActTag { static constexpr int value = ACT; };
+
+// Calls f(ActTag<act>{}) for the runtime activation code.
+template <typename F>
+__device__ __forceinline__ void dispatch_act(int act, F&& f) {
+    switch (act) {
+        case ACT_RELU: f(ActTag<ACT_RELU>{}); break;
+        case ACT_SWISH: f(ActTag<ACT_SWISH>{}); break;
+        case ACT_SIGMOID: f(ActTag<ACT_SIGMOID>{}); break;
+        case ACT_TANH: f(ActTag<ACT_TANH>{}); break;
+        default: f(ActTag<ACT_NONE>{}); break;
+    }
+}
+
 // 64-lane butterfly sum: every lane ends with the total.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -45,7 +45,7 @@ struct ConvParams {
 constexpr int BK = 16;       // K elements one wave consumes per step
 constexpr int EP_ROWS = 64;  // output rows per epilogue pass
 
-template <int BM, int BN, int WM, int WN, int KSPLIT, bool ONE_BY_ONE, bool GATE>
+template <int BM, int BN, int WM, int WN, int KSPLIT, bool ONE_BY_ONE, bool GATE, bool VEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int RM = TM / 32, RN = TN / 32;
@@ -75,54 +75,58 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int wm = KSPLIT > 1 ? 0 : wave / WN;
     const int wn = KSPLIT > 1 ? 0 : wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
-
-    // XCD-aware tile order: workgroups b and b+8 share an XCD, so give each of the 8 groups a
-    // contiguous range of tiles (n fastest): tiles that re-read the same activation rows share an L2.
-    int logical;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tile_n = logical % p.tiles_n;
-    const int tile_m = logical / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- per-thread staging coordinates (fixed over the K loop) ----
     const int kcx = tid % CPR;   // which float4 of the staged K slice
     const int srow = tid / CPR;
+
+    // ---- per-tile staging coordinates ----
+    int m0 = 0, n0 = 0;
     const float* a_base[RA];
     int a_hi0[RA], a_wi0[RA], a_b[RA];
     bool a_ok[RA];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int row = srow + RPI * i;
-        const int m = m0 + row;
-        a_ok[i] = (row < BM) && (m < p.M);
-        const int mm = a_ok[i] ? m : 0;
-        const int hw = p.Ho * p.Wo;
-        const int b = mm / hw;
-        const int rem = mm - b * hw;
-        const int ho = rem / p.Wo;
-        const int wo = rem - ho * p.Wo;
-        a_b[i] = b;
-        a_hi0[i] = ho * p.stride - p.pad_t;
-        a_wi0[i] = wo * p.stride - p.pad_l;
-        a_base[i] = p.x + (size_t)b * p.H * p.W * p.Cin;
-    }
     const float* b_base[RB];
     bool b_ok[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int row = srow + RPI * i;
-        const int n = n0 + row;
-        b_ok[i] = (row < BN) && (n < p.Cout);
-        b_base[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K;
-    }
 
-    // Staging registers for the tile in flight.  Every load below is unconditional (out-of-range
-    // elements read a valid dummy address and are zeroed when the tile is written to LDS) and nothing
-    // consumes a loaded value before lds_store(), so the loads of tile t+1 stay in flight behind the
-    // MFMAs of tile t instead of being waited for where they are issued.
+    // Workgroups are persistent: workgroup g handles tiles g, g + G, g + 2G, ... (G = gridDim.x, a
+    // multiple of 8).  Workgroups g and g + 8 share an XCD, so a tile index t always runs on XCD
+    // group t % 8; the remap below gives each group a contiguous range of tiles (n fastest), so
+    // tiles that re-read the same activation rows share an L2.
+    auto setup_tile = [&](int tl) {
+        const int xcd = tl & 7, q = p.nblk >> 3, r = p.nblk & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tl >> 3);
+        const int tile_n = logical % p.tiles_n;
+        const int tile_m = logical / p.tiles_n;
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int row = srow + RPI * i;
+            const int m = m0 + row;
+            a_ok[i] = (row < BM) && (m < p.M);
+            const int mm = a_ok[i] ? m : 0;
+            const int hw = p.Ho * p.Wo;
+            const int b = mm / hw;
+            const int rem = mm - b * hw;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            a_b[i] = b;
+            a_hi0[i] = ho * p.stride - p.pad_t;
+            a_wi0[i] = wo * p.stride - p.pad_l;
+            a_base[i] = p.x + (size_t)b * p.H * p.W * p.Cin;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int row = srow + RPI * i;
+            const int n = n0 + row;
+            b_ok[i] = (row < BN) && (n < p.Cout);
+            b_base[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K;
+        }
+    };
+
+    // Staging registers for the K slice in flight.  Every load below is unconditional (out-of-range
+    // elements read a valid dummy address and are zeroed when the slice is written to LDS) and nothing
+    // consumes a loaded value before lds_store(), so the loads of the next slice - or of the next
+    // tile's first slice - stay in flight behind the MFMAs and the epilogue instead of being waited
+    // for where they are issued.
     float4 ra[RA], rb[RB], rg[GATE ? RA : 1];
     unsigned okmask = 0;   // bit i: ra[i] valid, bit 16+i: rb[i] valid
 
@@ -161,139 +165,178 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             float4 v = ra[i];
             if (GATE) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
             if (!((okmask >> i) & 1u)) v = z;
-            if (row < BM) *reinterpret_cast<float4*>(&As[(buf * BM + row) * LDK + kcx * 4]) = v;
+            if (BM % RPI == 0 || row < BM) *reinterpret_cast<float4*>(&As[(buf * BM + row) * LDK + kcx * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int row = srow + RPI * i;
             const float4 v = ((okmask >> (16 + i)) & 1u) ? rb[i] : z;
-            if (row < BN) *reinterpret_cast<float4*>(&Bs[(buf * BN + row) * LDK + kcx * 4]) = v;
+            if (BN % RPI == 0 || row < BN) *reinterpret_cast<float4*>(&Bs[(buf * BN + row) * LDK + kcx * 4]) = v;
         }
     };
 
-    f32x16 acc[RM][RN];
-#pragma unroll
-    for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int j = 0; j < RN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
     const int nk = (p.K + BKS - 1) / BKS;
+    const int G = gridDim.x;
+    int tl = blockIdx.x;
+    if (tl >= p.nblk) return;
+    setup_tile(tl);
     gload(0);
-    lds_store(0);
-    __syncthreads();
 
-    int cur = 0;
-    for (int t = 0; t < nk; ++t) {
-        const bool more = (t + 1) < nk;
-        if (more) gload(t + 1);
-
-        // Lane (lr, lh) owns k = 8*lh + s of its wave's 16-wide slice for MFMA step s: any
-        // k -> (step, half) assignment is valid as long as A and B agree.
-        float af[RM][8], bf[RN][8];
-#pragma unroll
-        for (int i = 0; i < RM; ++i) {
-            const float* src = &As[(cur * BM + wm * TM + i * 32 + lr) * LDK + ks * BK + 8 * lh];
-            const float4 v0 = *reinterpret_cast<const float4*>(src);
-            const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-            af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
-            af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
-        }
-#pragma unroll
-        for (int j = 0; j < RN; ++j) {
-            const float* src = &Bs[(cur * BN + wn * TN + j * 32 + lr) * LDK + ks * BK + 8 * lh];
-            const float4 v0 = *reinterpret_cast<const float4*>(src);
-            const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-            bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
-            bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-
-        if (more) lds_store(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    // ---- epilogue: accumulators -> LDS (row-major tile) -> 16-B channel-contiguous stores ----
-    // A lane holds column n = lr and rows (e&3) + 8*(e>>2) + 4*lh of each 32x32 block.
-    float* ep = smem;  // [KSPLIT][EP_R][EP_LD]; the staging buffers are dead after the last barrier
+    float* ep = smem;  // [KSPLIT][EP_R][EP_LD]; aliases the staging buffers, used only between K loops
     constexpr int BN4 = BN / 4;
     constexpr int EP_RPI = 256 / BN4;
-    const int en4 = tid % BN4, erow = tid / BN4;
-    const int n = n0 + en4 * 4;
-    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.vec_ok) {
-        if (n < p.Cout) {
-            if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
-            if (p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + n);
-        }
-    } else {
-        float* s = reinterpret_cast<float*>(&sc4);
-        float* bb = reinterpret_cast<float*>(&bi4);
-        for (int u = 0; u < 4; ++u)
-            if (n + u < p.Cout) {
-                if (p.scale) s[u] = p.scale[n + u];
-                if (p.bias) bb[u] = p.bias[n + u];
-            }
-    }
     constexpr int NPASS = (BM + EP_ROWS - 1) / EP_ROWS;
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int r0 = pass * EP_ROWS;
-        if (wm * TM >= r0 && wm * TM < r0 + EP_ROWS) {
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh - r0;
-                        ep[(ks * EP_R + row) * EP_LD + wn * TN + j * 32 + lr] = acc[i][j][e];
-                    }
-        }
+    const int en4 = tid % BN4, erow = tid / BN4;
+
+    while (true) {
+        // registers hold K slice 0 of tile tl, staging coordinates describe tile tl
+        lds_store(0);
         __syncthreads();
-        for (int row = erow; row < EP_R; row += EP_RPI) {
-            const int m = m0 + r0 + row;
-            if (m >= p.M || n >= p.Cout) continue;
-            float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
+        const int em0 = m0, en0 = n0;
+        const int next = tl + G;
+        const bool has_next = next < p.nblk;
+
+        f32x16 acc[RM][RN];
 #pragma unroll
-            for (int k2 = 1; k2 < KSPLIT; ++k2) {
-                const float4 o = *reinterpret_cast<const float4*>(&ep[(k2 * EP_R + row) * EP_LD + en4 * 4]);
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        int cur = 0;
+        for (int t = 0; t < nk; ++t) {
+            const bool more = (t + 1) < nk;
+            if (more) {
+                gload(t + 1);
+            } else if (has_next) {   // prefetch the next tile's first slice; it lands during the epilogue
+                setup_tile(next);
+                gload(0);
             }
-            v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
-            v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
-            const size_t o = (size_t)m * p.ldy + n;
-            if (p.vec_ok) {
-                if (p.residual) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + o);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                }
-                v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act);
-                v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
-                *reinterpret_cast<float4*>(p.y + o) = v;
-            } else {
-                const float* vv = reinterpret_cast<const float*>(&v);
-                for (int u = 0; u < 4; ++u)
-                    if (n + u < p.Cout) {
-                        float t = vv[u];
-                        if (p.residual) t += p.residual[o + u];
-                        p.y[o + u] = act_apply(t, p.act);
-                    }
+
+            // Lane (lr, lh) owns k = 8*lh + s of its wave's 16-wide slice for MFMA step s: any
+            // k -> (step, half) assignment is valid as long as A and B agree.
+            float af[RM][8], bf[RN][8];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const float* src = &As[(cur * BM + wm * TM + i * 32 + lr) * LDK + ks * BK + 8 * lh];
+                const float4 v0 = *reinterpret_cast<const float4*>(src);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+                af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+                af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
             }
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const float* src = &Bs[(cur * BN + wn * TN + j * 32 + lr) * LDK + ks * BK + 8 * lh];
+                const float4 v0 = *reinterpret_cast<const float4*>(src);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+                bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
+                bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+
+            if (more) lds_store(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
         }
-        if (pass + 1 < NPASS) __syncthreads();
+
+        // ---- epilogue: accumulators -> LDS (row-major tile) -> 16-B channel-contiguous stores ----
+        // A lane holds column n = lr and rows (e&3) + 8*(e>>2) + 4*lh of each 32x32 block.
+        const int n = en0 + en4 * 4;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (VEC) {
+            if (n < p.Cout) {
+                if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
+                if (p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + n);
+            }
+        } else {
+            float* sp = reinterpret_cast<float*>(&sc4);
+            float* bp = reinterpret_cast<float*>(&bi4);
+            for (int u = 0; u < 4; ++u)
+                if (n + u < p.Cout) {
+                    if (p.scale) sp[u] = p.scale[n + u];
+                    if (p.bias) bp[u] = p.bias[n + u];
+                }
+        }
+        dispatch_act(p.act, [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int r0 = pass * EP_ROWS;
+                if (wm * TM >= r0 && wm * TM < r0 + EP_ROWS) {
+#pragma unroll
+                    for (int i = 0; i < RM; ++i)
+#pragma unroll
+                        for (int j = 0; j < RN; ++j)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int row = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh - r0;
+                                ep[(ks * EP_R + row) * EP_LD + wn * TN + j * 32 + lr] = acc[i][j][e];
+                            }
+                }
+                __syncthreads();
+                for (int row = erow; row < EP_R; row += EP_RPI) {
+                    const int m = em0 + r0 + row;
+                    if (m >= p.M || n >= p.Cout) continue;
+                    float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
+#pragma unroll
+                    for (int k2 = 1; k2 < KSPLIT; ++k2) {
+                        const float4 o = *reinterpret_cast<const float4*>(&ep[(k2 * EP_R + row) * EP_LD + en4 * 4]);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
+                    v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
+                    const size_t o = (size_t)m * p.ldy + n;
+                    if constexpr (VEC) {
+                        if (p.residual) {
+                            const float4 rr = *reinterpret_cast<const float4*>(p.residual + o);
+                            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                        }
+                        v.x = act_c<ACT>(v.x); v.y = act_c<ACT>(v.y); v.z = act_c<ACT>(v.z); v.w = act_c<ACT>(v.w);
+                        *reinterpret_cast<float4*>(p.y + o) = v;
+                    } else {
+                        const float* vv = reinterpret_cast<const float*>(&v);
+                        for (int u = 0; u < 4; ++u)
+                            if (n + u < p.Cout) {
+                                float t2 = vv[u];
+                                if (p.residual) t2 += p.residual[o + u];
+                                p.y[o + u] = act_c<ACT>(t2);
+                            }
+                    }
+                }
+                __syncthreads();   // the tile image is dead: the next pass / the next tile's slice 0 may overwrite it
+            }
+        });
+        if (!has_next) break;
+        tl = next;
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KSPLIT>
+// Persistent grid: enough workgroups to fill every CU at the kernel's own occupancy, a multiple of 8.
+// `cached` is a per-instantiation static owned by the caller (the value is idempotent, so a race between
+// host threads is benign).
+template <typename K>
+static int persistent_grid(K kernel, int nblk, int& cached) {
+    if (cached == 0) {
+        int dev = 0, cus = 256, per_cu = 2;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        (void)hipGetLastError();
+        cached = cus * per_cu;
+    }
+    int g = nblk < cached ? nblk : cached;
+    if (g >= 8) g &= ~7;
+    return g;
+}
+
+template <int BM, int BN, int WM, int WN, int KSPLIT, bool VEC = true>
 static int launch_cfg(ConvParams& p, hipStream_t st) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
@@ -304,15 +347,18 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
     }
     p.nblk = (int)blocks;
     const bool one = (p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0);
-    const dim3 grid((unsigned)blocks), block(256);
-    if (one && p.gate)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, true, true>), grid, block, 0, st, p);
-    else if (one)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, true, false>), grid, block, 0, st, p);
-    else if (p.gate)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, false, true>), grid, block, 0, st, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, false, false>), grid, block, 0, st, p);
+    const dim3 block(256);
+#define ICAP_LAUNCH(O_, G_)                                                                          \
+    do {                                                                                             \
+        static int cached = 0;                                                                       \
+        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, O_, G_, VEC>;                               \
+        hipLaunchKernelGGL(kern, dim3((unsigned)persistent_grid(kern, p.nblk, cached)), block, 0, st, p); \
+    } while (0)
+    if (one && p.gate) ICAP_LAUNCH(true, true);
+    else if (one) ICAP_LAUNCH(true, false);
+    else if (p.gate) ICAP_LAUNCH(false, true);
+    else ICAP_LAUNCH(false, false);
+#undef ICAP_LAUNCH
     return launch_status("conv_igemm");
 }
 
@@ -348,6 +394,9 @@ int conv_igemm_f32(const float* x, const float* w, const float* scale, const flo
                (!scale || aligned16(scale)) && (!bias || aligned16(bias));
     // Tile choice: wide N tiles when there are channels to fill them, tall M tiles for thin layers, and
     // for problems of only a few hundred rows a 32x32 tile whose four waves split K.
+    // Outputs whose rows are not 16-byte sliceable (Cout % 4 != 0, e.g. the 81-symbol char vocabulary) take
+    // one generic scalar-store configuration.
+    if (!p.vec_ok) return launch_cfg<64, 64, 2, 2, 1, false>(p, st);
     const long long tiles128 = ((M + 127) / 128) * ((Cout + 127) / 128);
     if (tiles128 < 256 && K >= 128) return launch_cfg<32, 32, 1, 1, 4>(p, st);
     if (M <= 1024) {

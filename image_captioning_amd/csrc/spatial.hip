@@ -105,17 +105,20 @@ __global__ __launch_bounds__(512) void dwconv_strip_kernel(
         const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 bi = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         float* yr = y + ((size_t)b * Ho * Wo + (size_t)ho * Wo) * C + c;
+        dispatch_act(act, [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-        for (int o = 0; o < TW; ++o) {
-            const int wo = wo0 + o;
-            if (wo < Wo) {
-                float4 v;
-                v.x = act_apply(fmaf(acc[o].x, sc.x, bi.x), act); v.y = act_apply(fmaf(acc[o].y, sc.y, bi.y), act);
-                v.z = act_apply(fmaf(acc[o].z, sc.z, bi.z), act); v.w = act_apply(fmaf(acc[o].w, sc.w, bi.w), act);
-                *reinterpret_cast<float4*>(yr + (size_t)wo * C) = v;
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            for (int o = 0; o < TW; ++o) {
+                const int wo = wo0 + o;
+                if (wo < Wo) {
+                    float4 v;
+                    v.x = act_c<ACT>(fmaf(acc[o].x, sc.x, bi.x)); v.y = act_c<ACT>(fmaf(acc[o].y, sc.y, bi.y));
+                    v.z = act_c<ACT>(fmaf(acc[o].z, sc.z, bi.z)); v.w = act_c<ACT>(fmaf(acc[o].w, sc.w, bi.w));
+                    *reinterpret_cast<float4*>(yr + (size_t)wo * C) = v;
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                }
             }
-        }
+        });
     }
     if (partial) {
         red[tid] = sum;

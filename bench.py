@@ -124,9 +124,11 @@ def main():
             return ev
         return None
 
-    for _ in range(args.warmup):
+    ops.set_autotune(True)      # the first warm-up pass times the tile configurations of every GEMM shape once
+    for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
+    ops.set_autotune(False)
     find_dominant()
     ops.set_trace(dom_trace)
 
@@ -181,8 +183,10 @@ def main():
 
 
 def breakdown(torch, ops, step, B):
+    ops.set_autotune(True)
     for _ in range(2):
         step()
+    ops.set_autotune(False)
     torch.cuda.synchronize()
     rec = []
     ops.set_trace(lambda n, s: rec.append((n, s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))) or rec[-1][2:])
@@ -198,8 +202,14 @@ def breakdown(torch, ops, step, B):
         rows.append((ms, n, s, fl / ms / 1e9, by / ms / 1e6))
         tot += ms
     print(f"step wall {wall:.3f} ms, traced launches {len(rec)} sum {tot:.3f} ms, batch {B}")
+    lib = __import__("image_captioning_amd._native", fromlist=["load"]).load()
     for ms, n, s, tf, gbs in rows:
-        print(f"{ms:9.4f} ms  {tf:8.2f} TFLOP/s {gbs:9.1f} GB/s  {n}{list(s)}")
+        cfg = ""
+        if n == "conv2d":
+            cfg = f" cfg={lib.icap_conv2d_tuned_config(s[0], s[1], s[2], s[3], s[4], s[5], s[5], s[6], s[7], s[8])}"
+        elif n == "linear":
+            cfg = f" cfg={lib.icap_conv2d_tuned_config(s[0], 1, 1, s[1], s[2], 1, 1, 1, 1, 1)}"
+        print(f"{ms:9.4f} ms  {tf:8.2f} TFLOP/s {gbs:9.1f} GB/s  {n}{list(s)}{cfg}")
 
 
 def cpu_baseline(torch, model, n):

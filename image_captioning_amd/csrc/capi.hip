@@ -20,6 +20,9 @@ void set_error(const char* fmt, ...) {
 // kernels implemented in the other translation units
 int conv_igemm_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int,
                    int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int conv_igemm_tune_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, int,
+                        int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int conv_igemm_tuned_cfg(int, int, int, int, int, int, int, int, int, int);
 int nchw_to_nhwc_pad_f32(const float*, float*, int, int, int, int, int, hipStream_t);
 int dwconv2d_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
                  int, int, int, int, int, hipStream_t);
@@ -72,6 +75,17 @@ int icap_conv2d_f32(const float* x, const float* w, const float* scale, const fl
                     int pad_t, int pad_l, int Ho, int Wo, int act, void* stream) {
     return conv_igemm_f32(x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo,
                           act, (hipStream_t)stream);
+}
+
+int icap_conv2d_tune_f32(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                         const float* gate, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                         int pad_t, int pad_l, int Ho, int Wo, int act, void* stream) {
+    return conv_igemm_tune_f32(x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho,
+                               Wo, act, (hipStream_t)stream);
+}
+
+int icap_conv2d_tuned_config(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo) {
+    return conv_igemm_tuned_cfg(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo);
 }
 
 int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y, float* partial,

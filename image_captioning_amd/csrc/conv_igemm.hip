@@ -23,6 +23,9 @@
 // and writes 16 B per lane along the channel axis (full 128-B lines per row).
 // Workgroup ids are remapped so that tiles sharing activation rows land on the
 // same XCD (its L2 then serves the re-reads).
+#include <map>
+#include <mutex>
+#include <tuple>
 #include "common.hpp"
 
 namespace icap {
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                             }
                 }
                 __syncthreads();
-                for (int row = erow; row < EP_R; row += EP_RPI) {
+                for (int row = erow; row < EP_R && erow < EP_RPI; row += EP_RPI) {
                     const int m = em0 + r0 + row;
                     if (m >= p.M || n >= p.Cout) continue;
                     float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
@@ -331,9 +334,8 @@ static int persistent_grid(K kernel, int nblk, int& cached) {
         (void)hipGetLastError();
         cached = cus * per_cu;
     }
-    int g = nblk < cached ? nblk : cached;
-    if (g >= 8) g &= ~7;
-    return g;
+    if (nblk <= cached) return nblk;   // one tile per workgroup: any count works with the XCD remap
+    return cached & ~7;                // several tiles per workgroup: the stride must keep tile % 8 fixed
 }
 
 template <int BM, int BN, int WM, int WN, int KSPLIT, bool VEC = true>
@@ -362,10 +364,42 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
     return launch_status("conv_igemm");
 }
 
-int conv_igemm_f32(const float* x, const float* w, const float* scale, const float* bias,
-                   const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
-                   int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
-                   hipStream_t st) {
+// ---------------------------------------------------------------- tile configurations
+// Every configuration computes the same result; they differ in how well they fill the chip for a given
+// (rows, channels, K).  conv_igemm_f32 picks one by a shape heuristic unless conv_igemm_tune_f32 has
+// measured the shape before, in which case the measured winner is used.
+typedef int (*LaunchFn)(ConvParams&, hipStream_t);
+struct TileCfg { int bm, bn, ksplit; LaunchFn fn; };
+static const TileCfg kCfgs[] = {
+    {128, 128, 1, launch_cfg<128, 128, 2, 2, 1>},   // 0
+    {256, 64, 1, launch_cfg<256, 64, 4, 1, 1>},     // 1
+    {256, 32, 1, launch_cfg<256, 32, 4, 1, 1>},     // 2
+    {128, 32, 1, launch_cfg<128, 32, 4, 1, 1>},     // 3
+    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1>},       // 4
+    {32, 32, 4, launch_cfg<32, 32, 1, 1, 4>},       // 5
+    {128, 96, 1, launch_cfg<128, 96, 4, 1, 1>},     // 6
+    {256, 96, 1, launch_cfg<256, 96, 4, 1, 1>},     // 7
+    {128, 64, 1, launch_cfg<128, 64, 2, 2, 1>},     // 8
+    {64, 128, 1, launch_cfg<64, 128, 2, 2, 1>},     // 9
+    {256, 128, 1, launch_cfg<256, 128, 4, 1, 1>},   // 10
+};
+constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+
+static int heuristic_cfg(long long M, int Cout, long long K) {
+    const long long tiles128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+    if (tiles128 < 256 && K >= 128) return 5;
+    if (M <= 1024) return Cout <= 32 ? 3 : 4;
+    if (Cout <= 32) return 2;
+    if (Cout <= 64) return 1;
+    return 0;
+}
+
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int> ShapeKey;  // B,H,W,Cin,Cout,KH,KW,stride,Ho,Wo
+static std::map<ShapeKey, int> g_tuned;
+static std::mutex g_tuned_mu;
+
+static int validate(const float* x, const float* w, const float* gate, float* y, int B, int H, int W, int Cin,
+                    int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo) {
     if (!x || !w || !y) { set_error("conv_igemm: null tensor"); return ICAP_ERR_ARG; }
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
         Ho <= 0 || Wo <= 0 || pad_t < 0 || pad_l < 0) {
@@ -388,24 +422,89 @@ int conv_igemm_f32(const float* x, const float* w, const float* scale, const flo
         set_error("conv_igemm: problem too large");
         return ICAP_ERR_LIMIT;
     }
+    return ICAP_OK;
+}
+
+static ConvParams make_params(const float* x, const float* w, const float* scale, const float* bias,
+                              const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
+                              int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act) {
     ConvParams p{x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW,
-                 stride, pad_t, pad_l, Ho, Wo, act, (int)M, (int)K, Cout, 0, 0, 0};
+                 stride, pad_t, pad_l, Ho, Wo, act, B * Ho * Wo, KH * KW * Cin, Cout, 0, 0, 0};
     p.vec_ok = (Cout % 4 == 0) && aligned16(y) && (!residual || aligned16(residual)) &&
                (!scale || aligned16(scale)) && (!bias || aligned16(bias));
-    // Tile choice: wide N tiles when there are channels to fill them, tall M tiles for thin layers, and
-    // for problems of only a few hundred rows a 32x32 tile whose four waves split K.
+    return p;
+}
+
+int conv_igemm_f32(const float* x, const float* w, const float* scale, const float* bias,
+                   const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
+                   int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                   hipStream_t st) {
+    const int rc = validate(x, w, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo);
+    if (rc != ICAP_OK) return rc;
+    ConvParams p = make_params(x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act);
     // Outputs whose rows are not 16-byte sliceable (Cout % 4 != 0, e.g. the 81-symbol char vocabulary) take
     // one generic scalar-store configuration.
     if (!p.vec_ok) return launch_cfg<64, 64, 2, 2, 1, false>(p, st);
-    const long long tiles128 = ((M + 127) / 128) * ((Cout + 127) / 128);
-    if (tiles128 < 256 && K >= 128) return launch_cfg<32, 32, 1, 1, 4>(p, st);
-    if (M <= 1024) {
-        if (Cout <= 32) return launch_cfg<128, 32, 4, 1, 1>(p, st);
-        return launch_cfg<64, 64, 2, 2, 1>(p, st);
+    int cfg = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        auto it = g_tuned.find(ShapeKey(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo));
+        if (it != g_tuned.end()) cfg = it->second;
     }
-    if (Cout <= 32) return launch_cfg<256, 32, 4, 1, 1>(p, st);
-    if (Cout <= 64) return launch_cfg<256, 64, 4, 1, 1>(p, st);
-    return launch_cfg<128, 128, 2, 2, 1>(p, st);
+    if (cfg < 0) cfg = heuristic_cfg(p.M, Cout, p.K);
+    return kCfgs[cfg].fn(p, st);
+}
+
+// Measures every tile configuration on this exact problem (the output is computed for real each time) and
+// remembers the fastest for later conv_igemm_f32 calls with the same shape.  Synchronises the stream: call it
+// once per shape while warming up, never inside a captured or latency-critical region.
+int conv_igemm_tune_f32(const float* x, const float* w, const float* scale, const float* bias,
+                        const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
+                        int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                        hipStream_t st) {
+    const int rc = validate(x, w, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo);
+    if (rc != ICAP_OK) return rc;
+    ConvParams p0 = make_params(x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act);
+    if (!p0.vec_ok) return conv_igemm_f32(x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, st);
+    const ShapeKey key(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo);
+    {
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        if (g_tuned.count(key)) return kCfgs[g_tuned[key]].fn(p0, st);
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { set_error("conv_igemm_tune: event creation failed"); return ICAP_ERR_HIP_BASE; }
+    int best = heuristic_cfg(p0.M, Cout, p0.K);
+    float best_ms = 1e30f;
+    for (int c = 0; c < kNumCfgs; ++c) {
+        // skip tiles that are mostly padding
+        if (kCfgs[c].bn >= 2 * Cout + 32 || (long long)kCfgs[c].bm >= 2 * (long long)p0.M + 64) continue;
+        if (kCfgs[c].ksplit > 1 && p0.K < 128) continue;
+        ConvParams p = p0;
+        int r = kCfgs[c].fn(p, st);   // warm-up (also loads the code object)
+        if (r != ICAP_OK) continue;
+        const int reps = 3;
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < reps; ++i) { p = p0; kCfgs[c].fn(p, st); }
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    {
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        g_tuned[key] = best;
+    }
+    ConvParams p = p0;
+    return kCfgs[best].fn(p, st);
+}
+
+int conv_igemm_tuned_cfg(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo) {
+    std::lock_guard<std::mutex> lk(g_tuned_mu);
+    auto it = g_tuned.find(ShapeKey(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo));
+    return it == g_tuned.end() ? -1 : it->second;
 }
 
 }  // namespace icap

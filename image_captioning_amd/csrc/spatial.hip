@@ -199,12 +199,32 @@ __global__ __launch_bounds__(256) void se_gate_kernel(
     float* __restrict__ gate, int C, int S) {
     __shared__ float pooled[SE_MAX_C];
     __shared__ float sq[SE_MAX_S];
+    __shared__ float red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* pb = partial + (size_t)b * nchunks * C;
-    for (int c = tid; c < C; c += 256) {
+    // Pool: sum the chunk partials of every channel.  With few channels and many chunks (early layers) the
+    // 256 threads split the chunk axis (KL lanes per channel, interleaved chunks) and combine through LDS in
+    // a fixed order, so the sum is still independent of scheduling.
+    int kl = 1;
+    while (kl * 2 * C <= 256 && kl * 2 <= nchunks) kl *= 2;
+    if (kl == 1) {
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f;
+            for (int k = 0; k < nchunks; ++k) s += pb[(size_t)k * C + c];
+            pooled[c] = s * inv_hw;
+        }
+    } else {
+        const int c = tid % C, l = tid / C;
         float s = 0.f;
-        for (int k = 0; k < nchunks; ++k) s += pb[(size_t)k * C + c];
-        pooled[c] = s * inv_hw;
+        if (l < kl)
+            for (int k = l; k < nchunks; k += kl) s += pb[(size_t)k * C + c];
+        red[tid] = s;
+        __syncthreads();
+        if (tid < C) {
+            float t = red[tid];
+            for (int j = 1; j < kl; ++j) t += red[j * C + tid];
+            pooled[tid] = t * inv_hw;
+        }
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;

@@ -19,6 +19,26 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# When True, conv2d / linear time every tile configuration the first time they see a shape (this synchronises
+# the stream once per new shape) and use the measured winner afterwards.  Enable while warming up a fixed workload.
+AUTOTUNE = False
+_tuned_shapes = set()
+
+
+def set_autotune(flag: bool) -> None:
+    global AUTOTUNE
+    AUTOTUNE = bool(flag)
+
+
+def _conv_entry(key):
+    """icap_conv2d_f32, or the tuning entry point the first time `key` is seen with autotune on."""
+    lib = N.load()
+    if AUTOTUNE and key not in _tuned_shapes:
+        _tuned_shapes.add(key)
+        return lib.icap_conv2d_tune_f32
+    return lib.icap_conv2d_f32
+
+
 # Optional launch tracer for measurement harnesses: a callable (op_name, signature) -> None or a pair of
 # torch.cuda.Event that are recorded on the launch stream immediately before and after the kernel.
 _trace = None
@@ -88,7 +108,7 @@ def conv2d(x, w, scale=None, bias=None, residual=None, gate=None, *, stride=1, p
         if v is not None and v.numel() != Cout:
             raise IcapError(f"conv2d: {nm} must have Cout={Cout} elements")
     span = _Span("conv2d", (B, H, W, Cin, Cout, KH, stride, Ho, Wo, residual is not None, gate is not None))
-    N.check(N.load().icap_conv2d_f32(
+    N.check(_conv_entry((B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo))(
         _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"),
         _ck(gate, "gate"), _ck(out, "out"), B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo, act, _stream()), "conv2d")
     span.done()
@@ -106,7 +126,7 @@ def linear(x, w, bias=None, scale=None, act=ACT_NONE, residual=None, out=None):
     if residual is not None and residual.numel() != M * Nn:
         raise IcapError("linear: residual has the wrong size")
     span = _Span("linear", (M, K, Nn, residual is not None))
-    N.check(N.load().icap_conv2d_f32(
+    N.check(_conv_entry((M, 1, 1, K, Nn, 1, 1, 1, 1, 1))(
         _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"), None,
         _ck(out, "out"), M, 1, 1, K, Nn, 1, 1, 1, 0, 0, 1, 1, act, _stream()), "linear")
     span.done()

@@ -60,6 +60,16 @@ int icap_conv2d_f32(const float* x, const float* w, const float* scale, const fl
                     int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
                     void* stream);
 
+/* Same computation as icap_conv2d_f32, but first times every tile configuration of the kernel on this
+ * exact problem and remembers the fastest for later icap_conv2d_f32 calls of the same shape (process-wide).
+ * SYNCHRONISES the stream: call once per shape during warm-up.  icap_conv2d_tuned_config returns the remembered
+ * configuration index, or -1.  No reference counterpart (the reference leaves kernel choice to cuDNN/MIOpen). */
+int icap_conv2d_tune_f32(const float* x, const float* w, const float* scale, const float* bias,
+                         const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
+                         int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                         void* stream);
+int icap_conv2d_tuned_config(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo);
+
 /* Depthwise KSxKS convolution (KS = 3 or 5) with fused scale/bias (folded
  * BatchNorm) and activation.  w is [KS*KS][C].  When `partial` is not NULL it
  * receives per-chunk channel sums of the OUTPUT, [B][icap_dwconv_chunks(Ho,Wo,C)][C],

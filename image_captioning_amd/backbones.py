@@ -305,7 +305,7 @@ class EfficientNetB0(nn.Module):
             d["dw_sb"] = fold_bn(b._bn1)
             sq = b._se_reduce.weight.shape[0]
             d["se"] = (b._se_reduce.weight.view(sq, mid).float().contiguous(), b._se_reduce.bias.float().contiguous(),
-                       b._se_expand.weight.view(mid, sq).float().contiguous(), b._se_expand.bias.float().contiguous())
+                       b._se_expand.weight.view(mid, sq).t().float().contiguous(), b._se_expand.bias.float().contiguous())   # [sq, mid]
             d["proj"] = (conv_weight_khwc(b._project_conv.weight), fold_bn(b._bn2))
             p["blocks"].append(d)
         p["head_w"] = conv_weight_khwc(self._conv_head.weight)

@@ -32,7 +32,10 @@ int embedding_f32(const float* table, const long long* idx, const float* add, fl
 }
 
 // ---------------------------------------------------------------- LayerNorm
-// y[r] = LN(x[r] + res[r % res_rows]) * gamma + beta ; one wave per row.
+// y[r] = LN(x[r] * pre_scale + res[r % res_rows]) * gamma + beta ; one wave per row.  Rows of up to
+// 64 * LN_MAXV elements are read once and kept in registers (mean, then centred variance, then output).
+constexpr int LN_MAXV = 16;
+
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                         int res_rows, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
@@ -42,25 +45,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (r >= rows) return;
     const float* xr = x + (size_t)r * E;
     const float* rr = res ? res + (size_t)(r % res_rows) * E : nullptr;
+    float v[LN_MAXV];
     float s = 0.f;
-    for (int e = lane; e < E; e += 64) {
-        float v = xr[e] * pre_scale;
-        if (rr) v += rr[e];
-        s += v;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int e = lane + 64 * i;
+        float t = 0.f;
+        if (e < E) {
+            t = xr[e] * pre_scale;
+            if (rr) t += rr[e];
+        }
+        v[i] = t;
+        s += t;
     }
     const float mean = wave_sum(s) / (float)E;
     float q = 0.f;
-    for (int e = lane; e < E; e += 64) {
-        float v = xr[e] * pre_scale;
-        if (rr) v += rr[e];
-        const float d = v - mean;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int e = lane + 64 * i;
+        const float d = (e < E) ? v[i] - mean : 0.f;
         q = fmaf(d, d, q);
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
-    for (int e = lane; e < E; e += 64) {
-        float v = xr[e] * pre_scale;
-        if (rr) v += rr[e];
-        y[(size_t)r * E + e] = (v - mean) * rstd * gamma[e] + beta[e];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int e = lane + 64 * i;
+        if (e < E) y[(size_t)r * E + e] = (v[i] - mean) * rstd * gamma[e] + beta[e];
     }
 }
 
@@ -70,6 +80,7 @@ int layernorm_f32(const float* x, const float* res, int res_rows, const float* g
         set_error("layernorm: bad arguments");
         return ICAP_ERR_ARG;
     }
+    if (E > 64 * LN_MAXV) { set_error("layernorm: E=%d exceeds %d", E, 64 * LN_MAXV); return ICAP_ERR_LIMIT; }
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, res, res ? res_rows : 1,
                        gamma, beta, y, rows, E, eps, pre_scale);
     return launch_status("layernorm");

@@ -189,7 +189,8 @@ int dwconv2d_f32(const float* x, const float* w, const float* scale, const float
 
 // ---------------------------------------------------------------- squeeze-excite gate
 // One workgroup per image: pooled = sum of chunk partials / HW; s = swish(Wr pooled + br);
-// gate = sigmoid(We s + be).
+// gate = sigmoid(We s + be).  Both weight matrices are stored [S][C] (the expand weight transposed) so that
+// every access is contiguous along the channel axis.
 constexpr int SE_MAX_C = 2048;
 constexpr int SE_MAX_S = 128;
 
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float a = be[c];
-        for (int j = 0; j < S; ++j) a = fmaf(we[(size_t)c * S + j], sq[j], a);
+        for (int j = 0; j < S; ++j) a = fmaf(we[(size_t)j * C + c], sq[j], a);   // we is [S][C]: coalesced over c
         gate[(size_t)b * C + c] = sigmoidf_(a);
     }
 }

@@ -157,7 +157,7 @@ def dwconv2d(x, w, scale=None, bias=None, *, ks, stride=1, pad=(0, 0, 0, 0), act
 def se_gate(partial, hw: int, wr, br, we, be):
     B, nchunks, Cc = partial.shape
     S = wr.shape[0]
-    if tuple(wr.shape) != (S, Cc) or tuple(we.shape) != (Cc, S) or br.numel() != S or be.numel() != Cc:
+    if tuple(wr.shape) != (S, Cc) or tuple(we.shape) != (S, Cc) or br.numel() != S or be.numel() != Cc:
         raise IcapError("se_gate: weight shapes do not match")
     gate = torch.empty((B, Cc), device=partial.device, dtype=torch.float32)
     N.check(N.load().icap_se_gate_f32(_ck(partial, "partial"), nchunks, 1.0 / hw, _ck(wr, "wr"), _ck(br, "br"),

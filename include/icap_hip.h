@@ -81,7 +81,7 @@ int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const 
 int icap_dwconv_chunks(int Ho, int Wo, int C);
 
 /* Squeeze-excite gate: gate[b][c] = sigmoid(We . swish(Wr . mean_hw(x) + br) + be),
- * from the chunk sums written by icap_dwconv2d_f32.  wr [S][C], we [C][S].
+ * from the chunk sums written by icap_dwconv2d_f32.  wr [S][C]; we [S][C] (the expand weight TRANSPOSED).
  * Replaces MBConv `_se_reduce` / `_se_expand` (transformer_word_level.py:13). */
 int icap_se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr, const float* br,
                      const float* we, const float* be, float* gate, int B, int C, int S, void* stream);

@@ -107,7 +107,7 @@ def test_dwconv_and_se(C, H, W, ks, s, pad):
     close(part.sum(1) / hw, ref.mean((2, 3)), what="dwconv partial pool")
     S = max(1, C // 24)
     wr, br, we, be = rnd(S, C, seed=5, scale=C ** -0.5), rnd(S, seed=6), rnd(C, S, seed=7, scale=S ** -0.5), rnd(C, seed=8)
-    gate = ops.se_gate(part, hw, wr.to(d), br.to(d), we.to(d), be.to(d))
+    gate = ops.se_gate(part, hw, wr.to(d), br.to(d), we.t().contiguous().to(d), be.to(d))
     sq = ref.mean((2, 3)) @ wr.t() + br
     sq = sq * torch.sigmoid(sq)
     close(gate, torch.sigmoid(sq @ we.t() + be), what="se gate")

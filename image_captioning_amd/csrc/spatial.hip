@@ -198,48 +198,70 @@ __global__ __launch_bounds__(256) void se_gate_kernel(
     const float* __restrict__ partial, int nchunks, float inv_hw, const float* __restrict__ wr,
     const float* __restrict__ br, const float* __restrict__ we, const float* __restrict__ be,
     float* __restrict__ gate, int C, int S) {
-    __shared__ float pooled[SE_MAX_C];
+    __shared__ __attribute__((aligned(16))) float pooled[SE_MAX_C];
     __shared__ float sq[SE_MAX_S];
-    __shared__ float red[256];
+    __shared__ __attribute__((aligned(16))) float4 red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int nq = C >> 2;
     const float* pb = partial + (size_t)b * nchunks * C;
-    // Pool: sum the chunk partials of every channel.  With few channels and many chunks (early layers) the
-    // 256 threads split the chunk axis (KL lanes per channel, interleaved chunks) and combine through LDS in
-    // a fixed order, so the sum is still independent of scheduling.
+    // Pool: sum the chunk partials of every channel quad.  The 256 threads cover (quad, chunk lane) pairs;
+    // with few channels and many chunks (early layers) several lanes split the chunk axis (interleaved) and
+    // are combined through LDS in a fixed order, so the sum is independent of scheduling.
     int kl = 1;
-    while (kl * 2 * C <= 256 && kl * 2 <= nchunks) kl *= 2;
-    if (kl == 1) {
-        for (int c = tid; c < C; c += 256) {
-            float s = 0.f;
-            for (int k = 0; k < nchunks; ++k) s += pb[(size_t)k * C + c];
-            pooled[c] = s * inv_hw;
+    while (kl * 2 * nq <= 256 && kl * 2 <= nchunks) kl *= 2;
+    for (int q0 = 0; q0 < nq; q0 += 256 / kl) {
+        const int ql = tid % (256 / kl), l = tid / (256 / kl);
+        const int q = q0 + ql;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq) {
+#pragma unroll 4
+            for (int k = l; k < nchunks; k += kl) {
+                const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)k * C + (q << 2));
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
         }
-    } else {
-        const int c = tid % C, l = tid / C;
-        float s = 0.f;
-        if (l < kl)
-            for (int k = l; k < nchunks; k += kl) s += pb[(size_t)k * C + c];
-        red[tid] = s;
-        __syncthreads();
-        if (tid < C) {
-            float t = red[tid];
-            for (int j = 1; j < kl; ++j) t += red[j * C + tid];
-            pooled[tid] = t * inv_hw;
+        if (kl > 1) {
+            red[tid] = s;
+            __syncthreads();
+            if (l == 0 && q < nq) {
+                for (int j = 1; j < kl; ++j) {
+                    const float4 o = red[j * (256 / kl) + ql];
+                    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+                }
+            }
+            __syncthreads();
+        }
+        if (l == 0 && q < nq) {
+            s.x *= inv_hw; s.y *= inv_hw; s.z *= inv_hw; s.w *= inv_hw;
+            *reinterpret_cast<float4*>(&pooled[q << 2]) = s;
         }
     }
     __syncthreads();
+    // Squeeze: one wave per output j, 16-byte weight loads, several j in flight per wave.
     const int wave = tid >> 6, lane = tid & 63;
     for (int j = wave; j < S; j += 4) {
         float a = 0.f;
-        for (int c = lane; c < C; c += 64) a = fmaf(wr[(size_t)j * C + c], pooled[c], a);
+        const float* wj = wr + (size_t)j * C;
+#pragma unroll 4
+        for (int q = lane; q < nq; q += 64)
+            a = dot4(*reinterpret_cast<const float4*>(wj + (q << 2)), *reinterpret_cast<const float4*>(&pooled[q << 2]), a);
         a = wave_sum(a);
         if (lane == 0) sq[j] = act_apply(a + br[j], ACT_SWISH);
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float a = be[c];
-        for (int j = 0; j < S; ++j) a = fmaf(we[(size_t)j * C + c], sq[j], a);   // we is [S][C]: coalesced over c
-        gate[(size_t)b * C + c] = sigmoidf_(a);
+    // Excite: this workgroup's slice of the channel quads (gridDim.y slices per image).
+    const int per = (nq + gridDim.y - 1) / gridDim.y;
+    const int q_lo = blockIdx.y * per, q_hi = min(nq, q_lo + per);
+    for (int q = q_lo + tid; q < q_hi; q += 256) {
+        float4 a = *reinterpret_cast<const float4*>(be + (q << 2));
+#pragma unroll 8
+        for (int j = 0; j < S; ++j) {
+            const float4 wv = *reinterpret_cast<const float4*>(we + (size_t)j * C + (q << 2));
+            const float sj = sq[j];
+            a.x = fmaf(wv.x, sj, a.x); a.y = fmaf(wv.y, sj, a.y); a.z = fmaf(wv.z, sj, a.z); a.w = fmaf(wv.w, sj, a.w);
+        }
+        a.x = sigmoidf_(a.x); a.y = sigmoidf_(a.y); a.z = sigmoidf_(a.z); a.w = sigmoidf_(a.w);
+        *reinterpret_cast<float4*>(gate + (size_t)b * C + (q << 2)) = a;
     }
 }
 
@@ -250,7 +272,15 @@ int se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr
         return ICAP_ERR_ARG;
     }
     if (C > SE_MAX_C || S > SE_MAX_S) { set_error("se_gate: C=%d S=%d exceed %d/%d", C, S, SE_MAX_C, SE_MAX_S); return ICAP_ERR_LIMIT; }
-    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), 0, st, partial, nchunks, inv_hw, wr, br, we, be, gate, C, S);
+    if (C % 4 || !aligned16(partial) || !aligned16(wr) || !aligned16(we) || !aligned16(be) || !aligned16(gate)) {
+        set_error("se_gate: C %% 4 and 16-byte alignment required");
+        return ICAP_ERR_ALIGN;
+    }
+    if (B > 65535) { set_error("se_gate: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
+    // several workgroups per image when there are enough channels to share out (each recomputes the cheap
+    // pooled / squeeze vectors and writes its own slice of the gate)
+    const int slices = C >= 960 ? 4 : (C >= 384 ? 2 : 1);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B, slices), dim3(256), 0, st, partial, nchunks, inv_hw, wr, br, we, be, gate, C, S);
     return launch_status("se_gate");
 }
 

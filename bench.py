@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per step per GPU")
     ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="images in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=384, help="images in the CPU-baseline sample")
     return ap.parse_args()
 
 

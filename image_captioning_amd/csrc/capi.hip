@@ -26,7 +26,7 @@ int conv_igemm_tuned_cfg(int, int, int, int, int, int, int, int, int, int);
 int nchw_to_nhwc_pad_f32(const float*, float*, int, int, int, int, int, hipStream_t);
 int dwconv2d_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
                  int, int, int, int, int, hipStream_t);
-int dwconv_chunks(int, int, int);
+int dwconv_chunks(int, int, int, int, int);
 int se_gate_f32(const float*, int, float, const float*, const float*, const float*, const float*, float*, int, int, int,
                 hipStream_t);
 int maxpool2d_f32(const float*, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -94,7 +94,7 @@ int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const 
     return dwconv2d_f32(x, w, scale, bias, y, partial, B, H, W, C, KS, stride, pad_t, pad_l, Ho, Wo, act, (hipStream_t)stream);
 }
 
-int icap_dwconv_chunks(int Ho, int Wo, int C) { return dwconv_chunks(Ho, Wo, C); }
+int icap_dwconv_chunks(int Ho, int Wo, int C, int KS, int stride) { return dwconv_chunks(Ho, Wo, C, KS, stride); }
 
 int icap_se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr, const float* br, const float* we,
                      const float* be, float* gate, int B, int C, int S, void* stream) {

@@ -52,70 +52,87 @@ int nchw_to_nhwc_pad_f32(const float* src, float* dst, int B, int C, int H, int 
 // pooled value does not depend on scheduling.
 constexpr int DW_TW = 7;   // divides every EfficientNet-B0 feature-map width (112, 56, 28, 14, 7)
 
-template <int KS, int S>
+template <int KS, int S, int TH>
 __global__ __launch_bounds__(512) void dwconv_strip_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
     const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ partial, int H, int W,
     int C, int pad_t, int pad_l, int Ho, int Wo, int act, int nq, int spb, int nstrips_w) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];
     constexpr int TW = DW_TW;
-    constexpr int NIN = (TW - 1) * S + KS;
+    constexpr int NIN = (TW - 1) * S + KS;     // input columns feeding one strip
+    constexpr int NROW = (TH - 1) * S + KS;    // input rows feeding TH vertically adjacent strips
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int ls = tid / nq;
     const int cq = tid - ls * nq;
-    const int strip = blockIdx.x * spb + ls;
-    const int nstrips = Ho * nstrips_w;
+    const int strip = blockIdx.x * spb + ls;                 // a "strip" is TH output rows x TW columns
+    const int nstrips = ((Ho + TH - 1) / TH) * nstrips_w;
     const bool active = (ls < spb) && (strip < nstrips);
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
         const int c = cq << 2;
-        const int ho = strip / nstrips_w;
-        const int wo0 = (strip - ho * nstrips_w) * TW;
-        const int hi0 = ho * S - pad_t, wi0 = wo0 * S - pad_l;
+        const int hs = strip / nstrips_w;
+        const int ho0 = hs * TH;
+        const int wo0 = (strip - hs * nstrips_w) * TW;
+        const int hi0 = ho0 * S - pad_t, wi0 = wo0 * S - pad_l;
         const float* xb = x + (size_t)b * H * W * C + c;
-        float4 acc[TW];
+        float4 acc[TH][TW];
 #pragma unroll
-        for (int o = 0; o < TW; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < TH; ++t)
 #pragma unroll
-        for (int r = 0; r < KS; ++r) {
-            const int hi = hi0 + r;
+            for (int o = 0; o < TW; ++o) acc[t][o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ri = 0; ri < NROW; ++ri) {
+            const int hi = hi0 + ri;
             const bool row_ok = (unsigned)hi < (unsigned)H;   // wave-divergent only at image borders
             if (!row_ok) continue;
-            float4 wr[KS];
-#pragma unroll
-            for (int q = 0; q < KS; ++q) wr[q] = *reinterpret_cast<const float4*>(w + (size_t)(r * KS + q) * C + c);
             const float* xr = xb + (size_t)hi * W * C;
+            float4 v[NIN];
 #pragma unroll
             for (int j = 0; j < NIN; ++j) {
                 const int wi = wi0 + j;
                 const bool ok = (unsigned)wi < (unsigned)W;
-                float4 v = *reinterpret_cast<const float4*>(ok ? xr + (size_t)wi * C : xr);   // always a valid address
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                v[j] = *reinterpret_cast<const float4*>(ok ? xr + (size_t)wi * C : xr);   // always a valid address
+                if (!ok) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-                for (int o = 0; o < TW; ++o) {
-                    const int q = j - o * S;
-                    if (q >= 0 && q < KS) {
-                        acc[o].x = fmaf(v.x, wr[q].x, acc[o].x); acc[o].y = fmaf(v.y, wr[q].y, acc[o].y);
-                        acc[o].z = fmaf(v.z, wr[q].z, acc[o].z); acc[o].w = fmaf(v.w, wr[q].w, acc[o].w);
+            for (int t = 0; t < TH; ++t) {
+                const int r = ri - t * S;                     // filter row this input row is for output row ho0 + t
+                if (r < 0 || r >= KS) continue;
+                float4 wr[KS];
+#pragma unroll
+                for (int q = 0; q < KS; ++q) wr[q] = *reinterpret_cast<const float4*>(w + (size_t)(r * KS + q) * C + c);
+#pragma unroll
+                for (int j = 0; j < NIN; ++j)
+#pragma unroll
+                    for (int o = 0; o < TW; ++o) {
+                        const int q = j - o * S;
+                        if (q >= 0 && q < KS) {
+                            acc[t][o].x = fmaf(v[j].x, wr[q].x, acc[t][o].x); acc[t][o].y = fmaf(v[j].y, wr[q].y, acc[t][o].y);
+                            acc[t][o].z = fmaf(v[j].z, wr[q].z, acc[t][o].z); acc[t][o].w = fmaf(v[j].w, wr[q].w, acc[t][o].w);
+                        }
                     }
-                }
             }
         }
         const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 bi = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float* yr = y + ((size_t)b * Ho * Wo + (size_t)ho * Wo) * C + c;
         dispatch_act(act, [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-            for (int o = 0; o < TW; ++o) {
-                const int wo = wo0 + o;
-                if (wo < Wo) {
-                    float4 v;
-                    v.x = act_c<ACT>(fmaf(acc[o].x, sc.x, bi.x)); v.y = act_c<ACT>(fmaf(acc[o].y, sc.y, bi.y));
-                    v.z = act_c<ACT>(fmaf(acc[o].z, sc.z, bi.z)); v.w = act_c<ACT>(fmaf(acc[o].w, sc.w, bi.w));
-                    *reinterpret_cast<float4*>(yr + (size_t)wo * C) = v;
-                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            for (int t = 0; t < TH; ++t) {
+                const int ho = ho0 + t;
+                if (ho >= Ho) continue;
+                float* yr = y + ((size_t)b * Ho * Wo + (size_t)ho * Wo) * C + c;
+#pragma unroll
+                for (int o = 0; o < TW; ++o) {
+                    const int wo = wo0 + o;
+                    if (wo < Wo) {
+                        float4 u;
+                        u.x = act_c<ACT>(fmaf(acc[t][o].x, sc.x, bi.x)); u.y = act_c<ACT>(fmaf(acc[t][o].y, sc.y, bi.y));
+                        u.z = act_c<ACT>(fmaf(acc[t][o].z, sc.z, bi.z)); u.w = act_c<ACT>(fmaf(acc[t][o].w, sc.w, bi.w));
+                        *reinterpret_cast<float4*>(yr + (size_t)wo * C) = u;
+                        sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
+                    }
                 }
             }
         });
@@ -134,8 +151,16 @@ __global__ __launch_bounds__(512) void dwconv_strip_kernel(
     }
 }
 
+// Rows per thread: two vertically adjacent strips share (KS - S) input rows in registers, which matters when
+// the filter is large against the stride; small images keep one row per thread so the grid still fills the chip.
+static int dwconv_th(int Ho, int Wo, int C, int KS, int stride) {
+    const long long threads2 = (long long)((Ho + 1) / 2) * ((Wo + DW_TW - 1) / DW_TW) * (C / 4);
+    (void)KS; (void)stride;
+    return threads2 >= 2048 ? 2 : 1;   // per image; the batch multiplies it
+}
+
 // Launch geometry shared by the kernel launcher and by callers sizing the partial buffer.
-static void dwconv_geometry(int Ho, int Wo, int C, int* block, int* spb, int* nblk) {
+static void dwconv_geometry(int Ho, int Wo, int C, int th, int* block, int* spb, int* nblk) {
     const int nq = C / 4;
     int best_bd = 0, best_spb = 1;
     double best_u = -1.0;
@@ -145,15 +170,15 @@ static void dwconv_geometry(int Ho, int Wo, int C, int* block, int* spb, int* nb
         const double u = (double)(s * nq) / bd;
         if (u > best_u + 1e-9) { best_u = u; best_bd = bd; best_spb = s; }
     }
-    const int nstrips = Ho * ((Wo + DW_TW - 1) / DW_TW);
+    const int nstrips = ((Ho + th - 1) / th) * ((Wo + DW_TW - 1) / DW_TW);
     if (best_spb > nstrips) best_spb = nstrips;
     *block = best_bd; *spb = best_spb; *nblk = (nstrips + best_spb - 1) / best_spb;
 }
 
-int dwconv_chunks(int Ho, int Wo, int C) {
+int dwconv_chunks(int Ho, int Wo, int C, int KS, int stride) {
     if (Ho <= 0 || Wo <= 0 || C <= 0 || C % 4 || C / 4 > 512) return -1;
     int bd, spb, nblk;
-    dwconv_geometry(Ho, Wo, C, &bd, &spb, &nblk);
+    dwconv_geometry(Ho, Wo, C, dwconv_th(Ho, Wo, C, KS, stride), &bd, &spb, &nblk);
     return nblk;
 }
 
@@ -173,11 +198,16 @@ int dwconv2d_f32(const float* x, const float* w, const float* scale, const float
     }
     if (B > 65535) { set_error("dwconv2d: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
     int bd, spb, nblk;
-    dwconv_geometry(Ho, Wo, C, &bd, &spb, &nblk);
+    const int th = dwconv_th(Ho, Wo, C, KS, stride);
+    dwconv_geometry(Ho, Wo, C, th, &bd, &spb, &nblk);
     const int nq = C / 4, nsw = (Wo + DW_TW - 1) / DW_TW;
     const dim3 grid(nblk, B), block(bd);
     const size_t lds = partial ? (size_t)bd * sizeof(float4) : 0;
-#define ICAP_DW(K_, S_) hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_>), grid, block, lds, st, x, w, scale, bias, y, partial, H, W, C, pad_t, pad_l, Ho, Wo, act, nq, spb, nsw)
+#define ICAP_DW(K_, S_)                                                                                                   \
+    do {                                                                                                                 \
+        if (th == 2) hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 2>), grid, block, lds, st, x, w, scale, bias, y, partial, H, W, C, pad_t, pad_l, Ho, Wo, act, nq, spb, nsw); \
+        else hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 1>), grid, block, lds, st, x, w, scale, bias, y, partial, H, W, C, pad_t, pad_l, Ho, Wo, act, nq, spb, nsw); \
+    } while (0)
     if (KS == 3 && stride == 1) ICAP_DW(3, 1);
     else if (KS == 3 && stride == 2) ICAP_DW(3, 2);
     else if (KS == 5 && stride == 1) ICAP_DW(5, 1);

@@ -145,7 +145,7 @@ def dwconv2d(x, w, scale=None, bias=None, *, ks, stride=1, pad=(0, 0, 0, 0), act
     lib = N.load()
     partial = None
     if want_partial:
-        partial = torch.empty((B, lib.icap_dwconv_chunks(Ho, Wo, Cc), Cc), device=x.device, dtype=torch.float32)
+        partial = torch.empty((B, lib.icap_dwconv_chunks(Ho, Wo, Cc, ks, stride), Cc), device=x.device, dtype=torch.float32)
     span = _Span("dwconv2d", (B, H, W, Cc, ks, stride, Ho, Wo))
     N.check(lib.icap_dwconv2d_f32(_ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(y, "y"),
                                   _ck(partial, "partial"), B, H, W, Cc, ks, stride, pt, pl, Ho, Wo, act, _stream()),

@@ -72,13 +72,13 @@ int icap_conv2d_tuned_config(int B, int H, int W, int Cin, int Cout, int KH, int
 
 /* Depthwise KSxKS convolution (KS = 3 or 5) with fused scale/bias (folded
  * BatchNorm) and activation.  w is [KS*KS][C].  When `partial` is not NULL it
- * receives per-chunk channel sums of the OUTPUT, [B][icap_dwconv_chunks(Ho,Wo,C)][C],
+ * receives per-chunk channel sums of the OUTPUT, [B][icap_dwconv_chunks(Ho,Wo,C,KS,stride)][C],
  * for the squeeze-excite pooling.  Replaces MBConv `_depthwise_conv` + `_bn1` +
  * swish of EfficientNet-B0 (transformer_word_level.py:13). */
 int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y,
                       float* partial, int B, int H, int W, int C, int KS, int stride, int pad_t, int pad_l,
                       int Ho, int Wo, int act, void* stream);
-int icap_dwconv_chunks(int Ho, int Wo, int C);
+int icap_dwconv_chunks(int Ho, int Wo, int C, int KS, int stride);
 
 /* Squeeze-excite gate: gate[b][c] = sigmoid(We . swish(Wr . mean_hw(x) + br) + be),
  * from the chunk sums written by icap_dwconv2d_f32.  wr [S][C]; we [S][C] (the expand weight TRANSPOSED).

@@ -36,5 +36,5 @@ def test_argument_checks_need_no_gpu():
     rc = lib.icap_conv2d_f32(None, None, None, None, None, None, None, 1, 1, 1, 4, 4, 1, 1, 1, 0, 0, 1, 1, 0, None)
     assert rc == 1 and b"null" in lib.icap_last_error()
     assert lib.icap_gemv_blocks(6756) > 0
-    assert lib.icap_dwconv_chunks(112, 112, 32) > 0 and lib.icap_dwconv_chunks(7, 7, 1152) == 7
+    assert lib.icap_dwconv_chunks(112, 112, 32, 3, 1) > 0 and lib.icap_dwconv_chunks(7, 7, 1152, 5, 1) == 7
     assert lib.icap_greedy_tfm_ws_floats(8, 512, 2048, 6756) > 8 * 512 * 4

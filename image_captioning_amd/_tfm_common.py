@@ -33,6 +33,20 @@ def _f32(t):
     return t.detach().float().contiguous()
 
 
+def pad_vocab_rows(w, bias, scale=None):
+    """Pad a vocabulary projection to a multiple of 4 rows (the fused arg-max GEMM writes 16-byte groups):
+    zero weight rows with a bias of -3e38 can never win the arg-max."""
+    V = w.shape[0]
+    pad = (-V) % 4
+    if pad == 0:
+        return w, bias, scale
+    w = torch.cat([w, w.new_zeros(pad, w.shape[1])]).contiguous()
+    bias = torch.cat([bias, bias.new_full((pad,), -3.0e38)]).contiguous()
+    if scale is not None:
+        scale = torch.cat([scale, scale.new_ones(pad)]).contiguous()
+    return w, bias, scale
+
+
 def _mha_weights(mha: nn.MultiheadAttention):
     E = mha.embed_dim
     w, b = mha.in_proj_weight, mha.in_proj_bias
@@ -187,7 +201,11 @@ class ImageCaptioningModelBase(nn.Module):
                     "ln2_g": p["ln2"][0], "ln2_b": p["ln2"][1], "ln3_g": p["ln3"][0], "ln3_b": p["ln3"][1],
                     "fc1_w": p["fc0"][0], "fc1_b": p["fc0"][1], "fc2_w": p["fc3"][0], "fc2_b": p["fc3"][1],
                     "out_w": p["out"][0], "out_b": p["out"][1]}
-        return self._prep.get(self, build)
+        def build_all():
+            wd = build()
+            wd["out_w4"], wd["out_b4"], _ = pad_vocab_rows(wd["out_w"], wd["out_b"])
+            return wd
+        return self._prep.get(self, build_all)
 
     def greedy_ids_from_features(self, img_embed, max_len, want_logits=False, lockstep=None):
         """Greedy decoding of every image as its own batch of one (the semantics of generate_caption,
@@ -215,22 +233,24 @@ class ImageCaptioningModelBase(nn.Module):
         return (ids, torch.cat(logits, 1)) if want_logits else ids
 
     def _greedy_gemm(self, wd, ca, start, max_len, want_logits):
-        """Large image batches: each step is a handful of [B, *] GEMMs on the matrix cores."""
+        """Large image batches: each step is three [B, *] GEMMs on the matrix cores plus two row kernels; the
+        vocabulary GEMM emits arg-max partials in its epilogue, and one kernel turns them into the token id and
+        the next step's LayerNorm2(embedding + cross-attention) row, so logits never make a round trip."""
         B = ca.shape[0]
         ids = torch.empty((B, max_len), device=ca.device, dtype=torch.int64)
-        tok = start
+        xin, _ = ops.embedding(wd["emb"], start, add=ca)
+        x = ops.layernorm(xin, wd["ln2_g"], wd["ln2_b"])
         all_logits = []
         for t in range(max_len):
-            xin, _ = ops.embedding(wd["emb"], tok, add=ca)
-            x = ops.layernorm(xin, wd["ln2_g"], wd["ln2_b"])
             h = ops.linear(x, wd["fc1_w"], wd["fc1_b"], act=ops.ACT_RELU)
-            f = ops.linear(h, wd["fc2_w"], wd["fc2_b"])
-            x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"], res=x)
-            logits = ops.linear(x2, wd["out_w"], wd["out_b"])
-            tok = ops.argmax_rows(logits)
-            ids[:, t].copy_(tok)
+            f = ops.linear(h, wd["fc2_w"], wd["fc2_b"], residual=x)
+            x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
+            pv, pi, logits = ops.linear_argmax(x2, wd["out_w4"], wd["out_b4"], want_logits=want_logits)
+            last = t + 1 == max_len
+            x = ops.next_token(pv, pi, ids, t, None if last else wd["emb"], None if last else ca,
+                               None if last else wd["ln2_g"], None if last else wd["ln2_b"])
             if want_logits:
-                all_logits.append(logits)
+                all_logits.append(logits[:, :wd["out_w"].shape[0]])
         return (ids, torch.stack(all_logits, 0)) if want_logits else ids
 
     def caption_ids(self, images, max_len=10):

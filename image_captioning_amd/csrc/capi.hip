@@ -23,6 +23,10 @@ int conv_igemm_f32(const float*, const float*, const float*, const float*, const
 int conv_igemm_tune_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, int,
                         int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int conv_igemm_tuned_cfg(int, int, int, int, int, int, int, int, int, int);
+int linear_argmax_parts(int);
+int linear_argmax_f32(const float*, const float*, const float*, const float*, float*, float*, int*, int, int, int, hipStream_t);
+int next_token_f32(const float*, const int*, int, long long*, int, const float*, const float*, const float*, const float*, float,
+                   float*, int, int, int, hipStream_t);
 int nchw_to_nhwc_pad_f32(const float*, float*, int, int, int, int, int, hipStream_t);
 int dwconv2d_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
                  int, int, int, int, int, hipStream_t);
@@ -86,6 +90,20 @@ int icap_conv2d_tune_f32(const float* x, const float* w, const float* scale, con
 
 int icap_conv2d_tuned_config(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo) {
     return conv_igemm_tuned_cfg(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo);
+}
+
+int icap_linear_argmax_f32(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                           float* part_val, int* part_idx, int M, int K, int N, void* stream) {
+    return linear_argmax_f32(x, w, scale, bias, y, part_val, part_idx, M, K, N, (hipStream_t)stream);
+}
+
+int icap_linear_argmax_parts(int N) { return linear_argmax_parts(N); }
+
+int icap_next_token_f32(const float* part_val, const int* part_idx, int nparts, long long* ids, int ids_stride,
+                        const float* table, const float* add, const float* gamma, const float* beta, float eps, float* out,
+                        int ldo, int rows, int E, void* stream) {
+    return next_token_f32(part_val, part_idx, nparts, ids, ids_stride, table, add, gamma, beta, eps, out, ldo, rows, E,
+                          (hipStream_t)stream);
 }
 
 int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y, float* partial,

@@ -43,6 +43,8 @@ struct ConvParams {
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act;
     int M, K, ldy;
     int tiles_n, nblk, vec_ok;
+    float* amax_val;        // optional [M][tiles_n]: per-tile row maxima of the outputs (arg-max partials)
+    int* amax_idx;          // their column indices
 };
 
 constexpr int BK = 16;       // K elements one wave consumes per step
@@ -289,7 +291,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 __syncthreads();
                 for (int row = erow; row < EP_R && erow < EP_RPI; row += EP_RPI) {
                     const int m = em0 + r0 + row;
+                    if constexpr (VEC && (BN4 & (BN4 - 1)) == 0) {
+                        if (p.amax_val) {
+                            // Row maximum over this tile's columns: the BN4 lanes that hold one row are contiguous
+                            // in the wave, so a width-BN4 butterfly reduces them; first index wins ties.
+                            float bv = -INFINITY;
+                            int bi = 0x7fffffff;
+                            if (m < p.M && n < p.Cout) {
+                                float4 t4 = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
+#pragma unroll
+                                for (int k2 = 1; k2 < KSPLIT; ++k2) {
+                                    const float4 o2 = *reinterpret_cast<const float4*>(&ep[(k2 * EP_R + row) * EP_LD + en4 * 4]);
+                                    t4.x += o2.x; t4.y += o2.y; t4.z += o2.z; t4.w += o2.w;
+                                }
+                                t4.x = act_c<ACT>(fmaf(t4.x, sc4.x, bi4.x)); t4.y = act_c<ACT>(fmaf(t4.y, sc4.y, bi4.y));
+                                t4.z = act_c<ACT>(fmaf(t4.z, sc4.z, bi4.z)); t4.w = act_c<ACT>(fmaf(t4.w, sc4.w, bi4.w));
+                                bv = t4.x; bi = n;
+                                argmax_combine(bv, bi, t4.y, n + 1);
+                                argmax_combine(bv, bi, t4.z, n + 2);
+                                argmax_combine(bv, bi, t4.w, n + 3);
+                            }
+#pragma unroll
+                            for (int o2 = BN4 / 2; o2 > 0; o2 >>= 1) {
+                                const float ov = __shfl_xor(bv, o2, 64);
+                                const int oi = __shfl_xor(bi, o2, 64);
+                                argmax_combine(bv, bi, ov, oi);
+                            }
+                            if (en4 == 0 && m < p.M) {
+                                p.amax_val[(size_t)m * p.tiles_n + en0 / BN] = bv;
+                                p.amax_idx[(size_t)m * p.tiles_n + en0 / BN] = bi;
+                            }
+                        }
+                    }
                     if (m >= p.M || n >= p.Cout) continue;
+                    if (!p.y) continue;
                     float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
 #pragma unroll
                     for (int k2 = 1; k2 < KSPLIT; ++k2) {
@@ -305,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                         }
                         v.x = act_c<ACT>(v.x); v.y = act_c<ACT>(v.y); v.z = act_c<ACT>(v.z); v.w = act_c<ACT>(v.w);
-                        *reinterpret_cast<float4*>(p.y + o) = v;
+                        if (p.y) *reinterpret_cast<float4*>(p.y + o) = v;
                     } else {
                         const float* vv = reinterpret_cast<const float*>(&v);
                         for (int u = 0; u < 4; ++u)
@@ -437,7 +472,7 @@ static ConvParams make_params(const float* x, const float* w, const float* scale
                               const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
                               int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act) {
     ConvParams p{x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW,
-                 stride, pad_t, pad_l, Ho, Wo, act, B * Ho * Wo, KH * KW * Cin, Cout, 0, 0, 0};
+                 stride, pad_t, pad_l, Ho, Wo, act, B * Ho * Wo, KH * KW * Cin, Cout, 0, 0, 0, nullptr, nullptr};
     p.vec_ok = (Cout % 4 == 0) && aligned16(y) && (!residual || aligned16(residual)) &&
                (!scale || aligned16(scale)) && (!bias || aligned16(bias));
     return p;
@@ -516,6 +551,25 @@ int conv_igemm_tune_f32(const float* x, const float* w, const float* scale, cons
     }
     ConvParams p = p0;
     return kCfgs[best].fn(p, st);
+}
+
+// Linear layer whose epilogue also emits, per output row and 64-column tile, the maximum and its column
+// (first index on ties): y (optional) [M][N], part_val / part_idx [M][linear_argmax_parts(N)].
+// Residual is not supported here (an arg-max over logits never has one).
+int linear_argmax_parts(int N) { return (N + 63) / 64; }
+
+int linear_argmax_f32(const float* x, const float* w, const float* scale, const float* bias, float* y, float* part_val,
+                      int* part_idx, int M, int K, int N, hipStream_t st) {
+    if (!part_val || !part_idx) { set_error("linear_argmax: null partial buffers"); return ICAP_ERR_ARG; }
+    float* yy = y ? y : reinterpret_cast<float*>(part_val);   // validate() needs a non-null, aligned output pointer
+    const int rc = validate(x, w, nullptr, yy, M, 1, 1, K, N, 1, 1, 1, 0, 0, 1, 1);
+    if (rc != ICAP_OK) return rc;
+    ConvParams p = make_params(x, w, scale, bias, nullptr, nullptr, yy, M, 1, 1, K, N, 1, 1, 1, 0, 0, 1, 1, ACT_NONE);
+    if (!p.vec_ok) { set_error("linear_argmax: N %% 4 and 16-byte aligned y / scale / bias required"); return ICAP_ERR_ALIGN; }
+    p.y = y;
+    p.amax_val = part_val;
+    p.amax_idx = part_idx;
+    return launch_cfg<64, 64, 2, 2, 1, 2>(p, st);
 }
 
 int conv_igemm_tuned_cfg(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo) {

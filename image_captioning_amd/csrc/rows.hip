@@ -138,6 +138,71 @@ int argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_stride,
     return launch_status("argmax_rows");
 }
 
+// ---------------------------------------------------------------- next token (arg-max finalize + gather + LayerNorm)
+// One wave per caption: reduce the arg-max partials of the vocabulary GEMM to the token id, store it at
+// ids[r * ids_stride], then build the next step's input row out[r] = LN(table[id] + add[r]) (LayerNorm only when
+// gamma is given; add optional).  Rows up to 64 * LN_MAXV wide.
+__global__ __launch_bounds__(256) void next_token_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
+                                                         int nparts, long long* __restrict__ ids, int ids_stride,
+                                                         const float* __restrict__ table, const float* __restrict__ add,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float* __restrict__ out, int ldo, int rows, int E) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int p = lane; p < nparts; p += 64) argmax_combine(bv, bi, part_val[(size_t)r * nparts + p], part_idx[(size_t)r * nparts + p]);
+    wave_argmax(bv, bi);
+    if (lane == 0) ids[(size_t)r * ids_stride] = bi;
+    if (!table) return;
+    const float* src = table + (size_t)bi * E;
+    float v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int e = lane + 64 * i;
+        float t = 0.f;
+        if (e < E) {
+            t = src[e];
+            if (add) t += add[(size_t)r * E + e];
+        }
+        v[i] = t;
+        s += t;
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (gamma) {
+        mean = wave_sum(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int e = lane + 64 * i;
+            const float d = (e < E) ? v[i] - mean : 0.f;
+            q = fmaf(d, d, q);
+        }
+        rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int e = lane + 64 * i;
+        if (e < E) out[(size_t)r * ldo + e] = gamma ? (v[i] - mean) * rstd * gamma[e] + beta[e] : v[i];
+    }
+}
+
+int next_token_f32(const float* part_val, const int* part_idx, int nparts, long long* ids, int ids_stride,
+                   const float* table, const float* add, const float* gamma, const float* beta, float eps, float* out,
+                   int ldo, int rows, int E, hipStream_t st) {
+    if (!part_val || !part_idx || !ids || nparts <= 0 || rows <= 0 || ids_stride <= 0 ||
+        (table && (!out || E <= 0 || ldo < E)) || (gamma && !beta)) {
+        set_error("next_token: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (table && E > 64 * LN_MAXV) { set_error("next_token: E=%d exceeds %d", E, 64 * LN_MAXV); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(next_token_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, part_val, part_idx, nparts, ids, ids_stride,
+                       table, add, gamma, beta, eps, out, ldo, rows, E);
+    return launch_status("next_token");
+}
+
 // ---------------------------------------------------------------- multi-head attention core
 // q: [Lq][N][E]  k, v: [Lk][Nk][E] with Nk == N or Nk == 1 (keys shared by every
 // batch column).  out[lq][n][h*hd + d] = sum_s softmax_s(q.k_s / sqrt(hd)) v_s.

@@ -215,6 +215,37 @@ def argmax_rows(logits, want_gap=False):
     return (idx, gap) if want_gap else idx
 
 
+def linear_argmax(x, w, bias=None, scale=None, want_logits=False):
+    """Vocabulary projection with fused arg-max partials -> (part_val [M,P], part_idx [M,P], logits or None)."""
+    M, K = x.shape
+    Nn = w.shape[0]
+    lib = N.load()
+    P = lib.icap_linear_argmax_parts(Nn)
+    pv = torch.empty((M, P), device=x.device, dtype=torch.float32)
+    pi = torch.empty((M, P), device=x.device, dtype=torch.int32)
+    y = torch.empty((M, Nn), device=x.device, dtype=torch.float32) if want_logits else None
+    span = _Span("linear", (M, K, Nn, False))
+    N.check(lib.icap_linear_argmax_f32(_ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(y, "y"),
+                                       _ck(pv, "pv"), _ck(pi, "pi", torch.int32), M, K, Nn, _stream()), "linear_argmax")
+    span.done()
+    return pv, pi, y
+
+
+def next_token(pv, pi, ids, step, table=None, add=None, gamma=None, beta=None, eps=1e-5):
+    """ids[:, step] = argmax from partials; returns LN(table[id] + add) (or the plain gathered rows, or None)."""
+    rows, P = pv.shape
+    out = None
+    E = 0
+    if table is not None:
+        E = table.shape[1]
+        out = torch.empty((rows, E), device=pv.device, dtype=torch.float32)
+    ids_ptr = _ck(ids, "ids", torch.int64) + 8 * step
+    N.check(N.load().icap_next_token_f32(_ck(pv, "pv"), _ck(pi, "pi", torch.int32), P, ids_ptr, ids.shape[1], _ck(table, "table"),
+                                         _ck(add, "add"), _ck(gamma, "gamma"), _ck(beta, "beta"), eps, _ck(out, "out"), max(E, 1),
+                                         rows, max(E, 1), _stream()), "next_token")
+    return out
+
+
 def mha_core(q, k, v, heads):
     """q [Lq,N,E]; k, v [Lk,Nk,E] with Nk in (N, 1)."""
     Lq, Nn, E = q.shape

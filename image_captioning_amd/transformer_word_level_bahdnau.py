@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401  (name kept for parity with the reference module)
 
 from . import ops
-from ._tfm_common import MAX_LOCKSTEP, _f32, _mha_weights, cut_before_end
+from ._tfm_common import MAX_LOCKSTEP, _f32, _mha_weights, cut_before_end, pad_vocab_rows
 from .backbones import EfficientNet, PreparedCache, fold_bn, get_cnn_model, require_eval  # noqa: F401
 
 
@@ -110,7 +110,8 @@ class BahdanauDecoder(nn.Module):
         w_ih = self.lstm.weight_ih.detach().float()
         scale, bias = fold_bn(self.fc[1], self.fc[0].bias)
         att = self.attention
-        return {"emb": _f32(self.embedding.weight),
+        fc_w4, fc_bias4, fc_scale4 = pad_vocab_rows(_f32(self.fc[0].weight), bias, scale)
+        return {"emb": _f32(self.embedding.weight), "fc_w4": fc_w4, "fc_bias4": fc_bias4, "fc_scale4": fc_scale4,
                 "w_ih": w_ih.contiguous(), "w_ih_e": w_ih[:, :E].contiguous(), "w_ih_c": w_ih[:, E:].contiguous(),
                 "w_hh": _f32(self.lstm.weight_hh), "b_ih": _f32(self.lstm.bias_ih), "b_hh": _f32(self.lstm.bias_hh),
                 "fc_w": _f32(self.fc[0].weight), "fc_scale": scale, "fc_bias": bias,
@@ -196,17 +197,17 @@ class ImageCaptioningModel(nn.Module):
         h = torch.zeros((B, H), device=dev, dtype=torch.float32)
         c = torch.zeros((B, H), device=dev, dtype=torch.float32)
         g_ctx = ops.linear(ctx, p["w_ih_c"], p["b_ih"])                                     # context half is step-invariant
-        tok, all_logits = start, []
+        emb, _ = ops.embedding(p["emb"], start)
+        all_logits = []
         for t in range(max_len):
-            emb, _ = ops.embedding(p["emb"], tok)
             g = ops.linear(emb, p["w_ih_e"], residual=g_ctx)
             g = ops.linear(h, p["w_hh"], p["b_hh"], residual=g)
             h, c = ops.lstm_pointwise(g, c)
-            logits = ops.linear(h, p["fc_w"], bias=p["fc_bias"], scale=p["fc_scale"])
-            tok = ops.argmax_rows(logits)
-            ids[:, t].copy_(tok)
+            pv, pi, logits = ops.linear_argmax(h, p["fc_w4"], bias=p["fc_bias4"], scale=p["fc_scale4"], want_logits=want_logits)
+            last = t + 1 == max_len
+            emb = ops.next_token(pv, pi, ids, t, None if last else p["emb"])
             if want_logits:
-                all_logits.append(logits)
+                all_logits.append(logits[:, :p["fc_w"].shape[0]])
         return (ids, torch.stack(all_logits, 0)) if want_logits else ids
 
     def caption_ids(self, images, max_len=10):

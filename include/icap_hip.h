@@ -131,6 +131,25 @@ int icap_bahdanau_attention_f32(const float* u, const float* w, const float* a_w
 int icap_lstm_pointwise_f32(const float* gates, const float* c_in, float* h_out, float* c_out, int B, int H, void* stream);
 int icap_gru_pointwise_f32(const float* gi, const float* gh, const float* h_in, float* h_out, int B, int H, void* stream);
 
+/* ------------------------------------------------------------------ decoder, batched (GEMM path) greedy step */
+
+/* Vocabulary projection with fused arg-max partials: y[M][N] = x[M][K] . w[N][K]^T * scale + bias (y may be
+ * NULL), plus per row and 64-column tile the maximum and its column, part_val / part_idx
+ * [M][icap_linear_argmax_parts(N)].  N % 4 == 0.  nn.Linear + argmax of one greedy step for a batch of
+ * independent captions: transformer_word_level.py:78 + the argmax form of TransformerTest.py:147-157;
+ * transformer_word_level_bahdnau.py:137 (+ folded BatchNorm1d). */
+int icap_linear_argmax_f32(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                           float* part_val, int* part_idx, int M, int K, int N, void* stream);
+int icap_linear_argmax_parts(int N);
+
+/* Finish the arg-max (ids[r*ids_stride] = token) and build the next step's input row
+ * out[r] = LayerNorm(table[token] + add[r]) (add optional; LayerNorm only when gamma != NULL; table NULL = ids only).
+ * transformer_word_level.py:105,75 (caption embedding, x + cross-attention, layer_norm2);
+ * transformer_word_level_bahdnau.py:133 (embedding). */
+int icap_next_token_f32(const float* part_val, const int* part_idx, int nparts, long long* ids, int ids_stride,
+                        const float* table, const float* add, const float* gamma, const float* beta, float eps,
+                        float* out, int ldo, int rows, int E, void* stream);
+
 /* ------------------------------------------------------------------ decoder, small-batch weight streaming */
 
 /* y[b][n] = act((W[n,:].x[b,:]) * scale[n] + bias[n]) for NB <= 8 rows of x.

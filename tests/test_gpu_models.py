@@ -68,8 +68,9 @@ def test_transformer(name, which):
     ids, logits = m.greedy_ids_from_features(feats, steps, want_logits=True)             # weight-streaming path
     H.assert_ids_match(ids.cpu().numpy(), g["ids_forced"], g["gaps"], name + " lock-step")
     close(logits[:3, 0], g["logits_img0"], "step logits")
-    ids2 = m.greedy_ids_from_features(feats, steps, lockstep=0)                          # GEMM path
+    ids2, logits2 = m.greedy_ids_from_features(feats, steps, want_logits=True, lockstep=0)   # GEMM path
     H.assert_ids_match(ids2.cpu().numpy(), g["ids_forced"], g["gaps"], name + " gemm")
+    close(logits2[:3, 0], g["logits_img0"], "step logits (gemm path)")
     for key in [k for k in g if k.startswith("fwd_caps_")]:
         shape = key[len("fwd_caps_"):]
         caps = torch.from_numpy(g[key]).to(dev())
@@ -93,8 +94,9 @@ def test_bahdanau(tag):
     ids, logits = m.greedy_ids_from_features(feats, 20, want_logits=True)
     H.assert_ids_match(ids.cpu().numpy(), g["ids_forced"], g["gaps"], "bahdanau lock-step")
     close(logits[:3, 0], g["logits_img0"], "step logits")
-    ids2 = m.greedy_ids_from_features(feats, 20, lockstep=0)
+    ids2, logits2 = m.greedy_ids_from_features(feats, 20, want_logits=True, lockstep=0)
     H.assert_ids_match(ids2.cpu().numpy(), g["ids_forced"], g["gaps"], "bahdanau gemm")
+    close(logits2[:3, 0], g["logits_img0"], "step logits (gemm path)")
     for key in [k for k in g if k.startswith("fwd_caps_")]:
         shape = key[len("fwd_caps_"):]
         caps = torch.from_numpy(g[key]).to(dev())

@@ -3,7 +3,7 @@
 // the caller's stream without touching the host in between.
 #include <stdarg.h>
 #include <stdio.h>
-#include "common.hpp"
+#include "decode.hpp"
 #include "../../include/icap_hip.h"
 
 namespace icap {
@@ -45,9 +45,6 @@ int lstm_pointwise_f32(const float*, const float*, float*, float*, int, int, hip
 int gru_pointwise_f32(const float*, const float*, const float*, float*, int, int, hipStream_t);
 int gemv_f32(const float*, const float*, const float*, const float*, int, float*, int, int, int, int, int, float*, int*,
              hipStream_t);
-int gemv_blocks(int);
-int argmax_finalize_f32(const float*, const int*, int, long long*, int, const float*, const float*, float*, int, int, int,
-                        hipStream_t);
 int lstm_cell_f32(const float*, const float*, const float*, const float*, const float*, int, const float*, const float*,
                   float*, float*, int, int, int, hipStream_t);
 int gru_cell_f32(const float*, const float*, const float*, const float*, const float*, int, const float*, float*, int, int,
@@ -183,11 +180,36 @@ int icap_gru_cell_f32(const float* w_ih, const float* w_hh, const float* b_ih, c
     return gru_cell_f32(w_ih, w_hh, b_ih, b_hh, x, ldx, h_in, h_out, NB, I, H, (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------ greedy decode drivers
+// A step is 2-3 launches: the first kernel of step t+1 reduces the arg-max partials the
+// vocabulary projection of step t left behind, stores token t and gathers its embedding row
+// (StepInput), so no kernel exists just to pick the token; one finalize launch after the
+// loop stores the last token.
+
+static StepInput token_input(const float* pv, const int* pi, int P, const long long* tok_in, long long* ids_out,
+                             int ids_stride, const float* table, int E, int rows) {
+    StepInput s;
+    s.table = table;
+    s.E = E;
+    s.table_rows = rows;
+    if (tok_in) {
+        s.tok_in = tok_in;
+    } else {
+        s.part_val = pv;
+        s.part_idx = pi;
+        s.nparts = P;
+        s.ids_out = ids_out;
+        s.ids_stride = ids_stride;
+    }
+    return s;
+}
+
 // ------------------------------------------------------------------ greedy: seq2seq LSTM / GRU
-// workspace (floats): x [NB][I] | h [2][layers][NB][H] | c [2][layers][NB][H] | part_val [NB][P] | part_idx [NB][P]
+// workspace (floats): h [2][layers][NB][H] | c [2][layers][NB][H] | part_val [NB][P] | part_idx [NB][P]
 long long icap_greedy_rnn_ws_floats(int NB, int layers, int H, int I, int V) {
     const long long P = gemv_blocks(V);
-    return align4((long long)NB * I) + 4LL * layers * align4((long long)NB * H) + 2 * align4((long long)NB * P);
+    (void)I;
+    return 4LL * layers * align4((long long)NB * H) + 2 * align4((long long)NB * P);
 }
 
 int icap_greedy_rnn_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, float* ws, int NB,
@@ -202,44 +224,40 @@ int icap_greedy_rnn_f32(const icap_rnn_weights* w, const float* x0, long long* i
     const int L = w->layers, H = w->H, I = w->I, V = w->V;
     const int P = gemv_blocks(V);
     const long long hsz = align4((long long)NB * H);
-    float* x = ws;
-    float* hbuf = x + align4((long long)NB * I);
+    float* hbuf = ws;
     float* cbuf = hbuf + 2LL * L * hsz;
     float* pv = cbuf + 2LL * L * hsz;
     int* pi = reinterpret_cast<int*>(pv + align4((long long)NB * P));
     // hidden=None in the reference means zero state (seq2seqbasic.py:74)
     hipError_t e = hipMemsetAsync(hbuf, 0, sizeof(float) * 4LL * L * hsz, st);
     if (e != hipSuccess) { set_error("greedy_rnn: memset: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
-    e = hipMemcpyAsync(x, x0, sizeof(float) * (size_t)NB * I, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) { set_error("greedy_rnn: copy: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
     int cur = 0;
     for (int t = 0; t < steps; ++t) {
-        const float* in = x;
-        int in_ld = I, in_w = I;
+        // step 0 consumes the image feature; later steps feature_fc(embed(previous token)) from in_table
+        StepInput in = t == 0 ? plain_input(x0, I) : token_input(pv, pi, P, nullptr, ids + (t - 1), steps, w->in_table, I, V);
+        int in_w = I;
         for (int l = 0; l < L; ++l) {
             const float* h_in = hbuf + (2LL * l + cur) * hsz;
             float* h_out = hbuf + (2LL * l + (cur ^ 1)) * hsz;
             const float* c_in = cbuf + (2LL * l + cur) * hsz;
             float* c_out = cbuf + (2LL * l + (cur ^ 1)) * hsz;
-            if (w->is_lstm)
-                ICAP_TRY(lstm_cell_f32(w->w_ih[l], w->w_hh[l], w->b_ih[l], w->b_hh[l], in, in_ld, h_in, c_in, h_out, c_out, NB, in_w, H, st));
-            else
-                ICAP_TRY(gru_cell_f32(w->w_ih[l], w->w_hh[l], w->b_ih[l], w->b_hh[l], in, in_ld, h_in, h_out, NB, in_w, H, st));
-            in = h_out; in_ld = H; in_w = H;
+            ICAP_TRY(rnn_cell_step_f32(w->is_lstm != 0, w->w_ih[l], w->w_hh[l], w->b_ih[l], w->b_hh[l], in, h_in, c_in, h_out,
+                                       c_out, NB, in_w, H, st));
+            in = plain_input(h_out, H);
+            in_w = H;
         }
         float* lo = logits_out ? logits_out + (size_t)t * NB * V : nullptr;
-        ICAP_TRY(gemv_f32(w->fc_w, nullptr, w->fc_b, in, H, lo, V, NB, V, H, ACT_NONE, pv, pi, st));
-        ICAP_TRY(argmax_finalize_f32(pv, pi, P, ids + t, steps, w->in_table, nullptr, x, I, I, NB, st));
+        ICAP_TRY(gemv_step_f32(w->fc_w, nullptr, w->fc_b, in, lo, V, NB, V, H, ACT_NONE, pv, pi, st));
         cur ^= 1;
     }
-    return ICAP_OK;
+    return argmax_finalize_f32(pv, pi, P, ids + (steps - 1), steps, nullptr, nullptr, nullptr, 0, 0, NB, st);
 }
 
 // ------------------------------------------------------------------ greedy: word / char transformer
-// workspace: xin [NB][E] | x [NB][E] | h [NB][FF] | y [NB][E] | x2 [NB][E] | part_val | part_idx
+// workspace: x [NB][E] | y [NB][E] | h [NB][FF] | part_val | part_idx
 long long icap_greedy_tfm_ws_floats(int NB, int E, int FF, int V) {
     const long long P = gemv_blocks(V);
-    return 4 * align4((long long)NB * E) + align4((long long)NB * FF) + 2 * align4((long long)NB * P);
+    return 2 * align4((long long)NB * E) + align4((long long)NB * FF) + 2 * align4((long long)NB * P);
 }
 
 int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
@@ -254,31 +272,41 @@ int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long l
     hipStream_t st = (hipStream_t)stream;
     const int E = w->E, FF = w->FF, V = w->V, P = gemv_blocks(V);
     const long long esz = align4((long long)NB * E);
-    float* xin = ws;
-    float* x = xin + esz;
+    float* x = ws;
     float* y = x + esz;
-    float* x2 = y + esz;
-    float* h = x2 + esz;
+    float* h = y + esz;
     float* pv = h + align4((long long)NB * FF);
     int* pi = reinterpret_cast<int*>(pv + align4((long long)NB * P));
-    ICAP_TRY(embedding_f32(w->emb, start_ids, ca, xin, E, NB, E, V, nullptr, st));
     for (int t = 0; t < steps; ++t) {
-        ICAP_TRY(layernorm_f32(xin, nullptr, 1, w->ln2_g, w->ln2_b, x, NB, E, 1e-5f, 1.f, st));
-        ICAP_TRY(gemv_f32(w->fc1_w, nullptr, w->fc1_b, x, E, h, FF, NB, FF, E, ACT_RELU, nullptr, nullptr, st));
-        ICAP_TRY(gemv_f32(w->fc2_w, nullptr, w->fc2_b, h, FF, y, E, NB, E, FF, ACT_NONE, nullptr, nullptr, st));
-        ICAP_TRY(layernorm_f32(y, x, NB, w->ln3_g, w->ln3_b, x2, NB, E, 1e-5f, 1.f, st));
+        // x = LN2(embedding(token) + cross-attention row); h = relu(fc1 x)
+        StepInput in1 = token_input(pv, pi, P, t == 0 ? start_ids : nullptr, ids + (t - 1), steps, w->emb, E, V);
+        in1.add = ca;
+        in1.ld_add = E;
+        in1.ln_g = w->ln2_g;
+        in1.ln_b = w->ln2_b;
+        in1.x_out = x;
+        in1.ld_xout = E;
+        ICAP_TRY(gemv_step_f32(w->fc1_w, nullptr, w->fc1_b, in1, h, FF, NB, FF, E, ACT_RELU, nullptr, nullptr, st));
+        ICAP_TRY(gemv_step_f32(w->fc2_w, nullptr, w->fc2_b, plain_input(h, FF), y, E, NB, E, FF, ACT_NONE, nullptr, nullptr, st));
+        // logits = out(LN3(x + y))
+        StepInput in3 = plain_input(y, E);
+        in3.add = x;
+        in3.ld_add = E;
+        in3.ln_g = w->ln3_g;
+        in3.ln_b = w->ln3_b;
         float* lo = logits_out ? logits_out + (size_t)t * NB * V : nullptr;
-        ICAP_TRY(gemv_f32(w->out_w, nullptr, w->out_b, x2, E, lo, V, NB, V, E, ACT_NONE, pv, pi, st));
-        ICAP_TRY(argmax_finalize_f32(pv, pi, P, ids + t, steps, w->emb, ca, xin, E, E, NB, st));
+        ICAP_TRY(gemv_step_f32(w->out_w, nullptr, w->out_b, in3, lo, V, NB, V, E, ACT_NONE, pv, pi, st));
     }
-    return ICAP_OK;
+    return argmax_finalize_f32(pv, pi, P, ids + (steps - 1), steps, nullptr, nullptr, nullptr, 0, 0, NB, st);
 }
 
 // ------------------------------------------------------------------ greedy: Bahdanau LSTMCell decoder
-// workspace: x [NB][E+ENC] | h [2][NB][H] | c [2][NB][H] | part_val | part_idx
+// workspace: h [2][NB][H] | c [2][NB][H] | part_val | part_idx
 long long icap_greedy_bah_ws_floats(int NB, int E, int ENC, int H, int V) {
     const long long P = gemv_blocks(V);
-    return align4((long long)NB * (E + ENC)) + 4 * align4((long long)NB * H) + 2 * align4((long long)NB * P);
+    (void)E;
+    (void)ENC;
+    return 4 * align4((long long)NB * H) + 2 * align4((long long)NB * P);
 }
 
 int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
@@ -293,30 +321,28 @@ int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC
     hipStream_t st = (hipStream_t)stream;
     const int E = w->E, H = w->H, V = w->V, I = E + ENC, P = gemv_blocks(V);
     const long long hsz = align4((long long)NB * H);
-    float* x = ws;
-    float* hbuf = x + align4((long long)NB * I);
+    float* hbuf = ws;
     float* cbuf = hbuf + 2 * hsz;
     float* pv = cbuf + 2 * hsz;
     int* pi = reinterpret_cast<int*>(pv + align4((long long)NB * P));
     hipError_t e = hipMemsetAsync(hbuf, 0, sizeof(float) * 4 * hsz, st);  // init_hidden_state: zeros
     if (e != hipSuccess) { set_error("greedy_bah: memset: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
-    // x[b] = [ emb[start] | context[b] ]; the context half never changes
-    e = hipMemcpy2DAsync(x + E, sizeof(float) * I, context, sizeof(float) * ENC, sizeof(float) * ENC, NB, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) { set_error("greedy_bah: copy: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
-    ICAP_TRY(embedding_f32(w->emb, start_ids, nullptr, x, I, NB, E, V, nullptr, st));
     int cur = 0;
     for (int t = 0; t < steps; ++t) {
         const float* h_in = hbuf + cur * hsz;
         float* h_out = hbuf + (cur ^ 1) * hsz;
         const float* c_in = cbuf + cur * hsz;
         float* c_out = cbuf + (cur ^ 1) * hsz;
-        ICAP_TRY(lstm_cell_f32(w->w_ih, w->w_hh, w->b_ih, w->b_hh, x, I, h_in, c_in, h_out, c_out, NB, I, H, st));
+        // x[b] = [ emb[token] | context[b] ]; the context half never changes
+        StepInput in = token_input(pv, pi, P, t == 0 ? start_ids : nullptr, ids + (t - 1), steps, w->emb, E, V);
+        in.tail = context;
+        in.ld_tail = ENC;
+        ICAP_TRY(rnn_cell_step_f32(true, w->w_ih, w->w_hh, w->b_ih, w->b_hh, in, h_in, c_in, h_out, c_out, NB, I, H, st));
         float* lo = logits_out ? logits_out + (size_t)t * NB * V : nullptr;
-        ICAP_TRY(gemv_f32(w->fc_w, w->fc_scale, w->fc_bias, h_out, H, lo, V, NB, V, H, ACT_NONE, pv, pi, st));
-        ICAP_TRY(argmax_finalize_f32(pv, pi, P, ids + t, steps, w->emb, nullptr, x, I, E, NB, st));
+        ICAP_TRY(gemv_step_f32(w->fc_w, w->fc_scale, w->fc_bias, plain_input(h_out, H), lo, V, NB, V, H, ACT_NONE, pv, pi, st));
         cur ^= 1;
     }
-    return ICAP_OK;
+    return argmax_finalize_f32(pv, pi, P, ids + (steps - 1), steps, nullptr, nullptr, nullptr, 0, 0, NB, st);
 }
 
 }  // extern "C"

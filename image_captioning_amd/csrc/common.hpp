@@ -75,17 +75,41 @@ __device__ __forceinline__ void dispatch_act(int act, F&& f) {
     }
 }
 
-// 64-lane butterfly sum: every lane ends with the total.
+// Wave-wide reductions.  All 64 lanes of the wave must be active.  Lanes exchange
+// values with DPP modifiers inside each row of 16 (a few cycles each, against
+// >100 cycles for every LDS-crossbar ds_bpermute a shuffle compiles to) and the four
+// row results meet through v_readlane; every lane ends with the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+constexpr int DPP_QUAD_SWAP1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_SWAP2 = 0x4E;   // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // reverse within 8 lanes
+constexpr int DPP_ROW_MIRROR = 0x140;  // reverse within 16 lanes
+
+__device__ __forceinline__ float lane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<DPP_QUAD_SWAP1>(v);
+    v += dpp_f<DPP_QUAD_SWAP2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<DPP_QUAD_SWAP1>(v));
+    v = fmaxf(v, dpp_f<DPP_QUAD_SWAP2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 
 // (value, index) max with first-index tie-break, the order torch.argmax uses.
@@ -93,13 +117,24 @@ __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int o
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp(float& v, int& i) {
+    const float ov = dpp_f<CTRL>(v);
+    const int oi = dpp_i<CTRL>(i);
+    argmax_combine(v, i, ov, oi);
+}
+
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
+    argmax_dpp<DPP_QUAD_SWAP1>(v, i);
+    argmax_dpp<DPP_QUAD_SWAP2>(v, i);
+    argmax_dpp<DPP_HALF_MIRROR>(v, i);
+    argmax_dpp<DPP_ROW_MIRROR>(v, i);
+    float bv = lane_f(v, 0);
+    int bi = __builtin_amdgcn_readlane(i, 0);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(v, o, 64);
-        int oi = __shfl_xor(i, o, 64);
-        argmax_combine(v, i, ov, oi);
-    }
+    for (int r = 16; r < 64; r += 16) argmax_combine(bv, bi, lane_f(v, r), __builtin_amdgcn_readlane(i, r));
+    v = bv;
+    i = bi;
 }
 
 __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {

@@ -26,6 +26,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace icap {
@@ -50,14 +51,21 @@ struct ConvParams {
 constexpr int BK = 16;       // K elements one wave consumes per step
 constexpr int EP_ROWS = 64;  // output rows per epilogue pass
 
-template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+template <int S>
+struct SetTag { static constexpr int value = S; };
+
+// PF2: two K slices in flight in registers instead of one (needs an even number of K steps).  A
+// workgroup that is alone on its CU - few-tile problems such as the decoder GEMMs at 256 rows -
+// otherwise stalls every step for the part of the memory latency one step of MFMAs does not cover.
+template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC, bool PF2 = false>
+__global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int NT = 64 * WM * WN * KSPLIT;   // threads: one wave per (row block, column block, K split)
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int RM = TM / 32, RN = TN / 32;
     constexpr int CPR = 4 * KSPLIT * KU;      // float4 chunks per staged row
     constexpr int BKS = BK * KSPLIT * KU;     // K elements staged per step (each wave consumes KU 16-wide slices of it)
     constexpr int LDK = BKS + 4;              // padded LDS row (floats)
-    constexpr int RPI = 256 / CPR;            // rows staged per pass of the 256 threads
+    constexpr int RPI = NT / CPR;             // rows staged per pass of the workgroup
     constexpr int RA = (BM + RPI - 1) / RPI;
     constexpr int RB = (BN + RPI - 1) / RPI;
     constexpr int EP_LD = BN + 4;
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int STAGE_FLOATS = 2 * (BM + BN) * LDK;
     constexpr int EP_FLOATS = KSPLIT * EP_R * EP_LD;
     constexpr int SMEM_FLOATS = STAGE_FLOATS > EP_FLOATS ? STAGE_FLOATS : EP_FLOATS;
-    static_assert(WM * WN * KSPLIT == 4, "four waves per workgroup");
+    static_assert(NT >= 256 && NT <= 1024 && NT % CPR == 0, "4 to 16 waves per workgroup");
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is built from 32x32 blocks");
 
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
@@ -131,10 +139,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // consumes a loaded value before lds_store(), so the loads of the next slice - or of the next
     // tile's first slice - stay in flight behind the MFMAs and the epilogue instead of being waited
     // for where they are issued.
-    float4 ra[RA], rb[RB], rg[GATE ? RA : 1];
-    unsigned okmask = 0;   // bit i: ra[i] valid, bit 16+i: rb[i] valid
+    constexpr int NSET = PF2 ? 2 : 1;
+    float4 ra[NSET][RA], rb[NSET][RB], rg[NSET][GATE ? RA : 1];
+    unsigned okmask_s[NSET];   // bit i: ra[i] valid, bit 16+i: rb[i] valid
 
-    auto gload = [&](int t) {
+    auto gload = [&](int t, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
         const int kk = t * BKS + kcx * 4;
         const bool kin = kk < p.K;
         int r = 0, q = 0, c = kk;
@@ -144,37 +154,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             r = tap / p.KW;
             q = tap - r * p.KW;
         }
-        okmask = 0;
+        unsigned okmask = 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int hi = a_hi0[i] + r, wi = a_wi0[i] + q;
             const bool ok = kin && a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             const float* src = ok ? a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + c : p.x;
-            ra[i] = *reinterpret_cast<const float4*>(src);
-            if (GATE) rg[i] = *reinterpret_cast<const float4*>(ok ? p.gate + (size_t)a_b[i] * p.Cin + c : p.gate);
+            ra[S][i] = *reinterpret_cast<const float4*>(src);
+            if (GATE) rg[S][i] = *reinterpret_cast<const float4*>(ok ? p.gate + (size_t)a_b[i] * p.Cin + c : p.gate);
             okmask |= ok ? (1u << i) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const bool ok = kin && b_ok[i];
-            rb[i] = *reinterpret_cast<const float4*>(ok ? b_base[i] + kk : p.w);
+            rb[S][i] = *reinterpret_cast<const float4*>(ok ? b_base[i] + kk : p.w);
             okmask |= ok ? (1u << (16 + i)) : 0u;
         }
+        okmask_s[S] = okmask;
     };
-    auto lds_store = [&](int buf) {
+    auto lds_store = [&](int buf, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        const unsigned okmask = okmask_s[S];
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int row = srow + RPI * i;
-            float4 v = ra[i];
-            if (GATE) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+            float4 v = ra[S][i];
+            if (GATE) { v.x *= rg[S][i].x; v.y *= rg[S][i].y; v.z *= rg[S][i].z; v.w *= rg[S][i].w; }
             if (!((okmask >> i) & 1u)) v = z;
             if (BM % RPI == 0 || row < BM) *reinterpret_cast<float4*>(&As[(buf * BM + row) * LDK + kcx * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int row = srow + RPI * i;
-            const float4 v = ((okmask >> (16 + i)) & 1u) ? rb[i] : z;
+            const float4 v = ((okmask >> (16 + i)) & 1u) ? rb[S][i] : z;
             if (BN % RPI == 0 || row < BN) *reinterpret_cast<float4*>(&Bs[(buf * BN + row) * LDK + kcx * 4]) = v;
         }
     };
@@ -184,17 +197,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     int tl = blockIdx.x;
     if (tl >= p.nblk) return;
     setup_tile(tl);
-    gload(0);
+    gload(0, SetTag<0>{});
+    if constexpr (PF2) gload(1, SetTag<1>{});
 
     float* ep = smem;  // [KSPLIT][EP_R][EP_LD]; aliases the staging buffers, used only between K loops
     constexpr int BN4 = BN / 4;
-    constexpr int EP_RPI = 256 / BN4;
+    constexpr int EP_RPI = NT / BN4;
     constexpr int NPASS = (BM + EP_ROWS - 1) / EP_ROWS;
     const int en4 = tid % BN4, erow = tid / BN4;
 
     while (true) {
-        // registers hold K slice 0 of tile tl, staging coordinates describe tile tl
-        lds_store(0);
+        // registers hold K slice 0 (and 1 with PF2) of tile tl, staging coordinates describe tile tl
+        lds_store(0, SetTag<0>{});
         __syncthreads();
         const int em0 = m0, en0 = n0;
         const int next = tl + G;
@@ -209,17 +223,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
         int cur = 0;
-        for (int t = 0; t < nk; ++t) {
-            const bool more = (t + 1) < nk;
-            if (more) {
-                gload(t + 1);
-            } else if (has_next) {   // prefetch the next tile's first slice; it lands during the epilogue
-                setup_tile(next);
-                gload(0);
-            }
-
-            // Lane (lr, lh) owns k = 8*lh + s of a 16-wide slice for MFMA step s: any k -> (step, half)
-            // assignment is valid as long as A and B agree.  Wave ks consumes slices ks*KU .. ks*KU+KU-1.
+        // MFMAs over the staged slice in LDS buffer `cur`.
+        // Lane (lr, lh) owns k = 8*lh + s of a 16-wide slice for MFMA step s: any k -> (step, half)
+        // assignment is valid as long as A and B agree.  Wave ks consumes slices ks*KU .. ks*KU+KU-1.
+        auto compute = [&]() {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 float af[RM][8], bf[RN][8];
@@ -248,10 +255,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                         for (int j = 0; j < RN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
             }
+        };
 
-            if (more) lds_store(cur ^ 1);
+        if constexpr (PF2) {
+            // Step t fetches slice t+2 into the register set slice t came from, multiplies slice t, then
+            // moves slice t+1 (fetched a whole step earlier) into the other LDS buffer.  The steady-state
+            // loop body is branch-free so that the compiler's wait counts let the newest fetch stay in
+            // flight across the LDS store; the last two steps fetch the next tile's slices 0 and 1
+            // (nk is even, so they land in sets 0 and 1 again).
+            for (int t = 0; t + 2 < nk; t += 2) {
+                // the scheduling fences keep the compiler from hoisting the store's use of fetched
+                // registers (and with it a full wait) above the MFMAs
+                gload(t + 2, SetTag<0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                compute();
+                __builtin_amdgcn_sched_barrier(0);
+                lds_store(cur ^ 1, SetTag<1>{});
+                __syncthreads();
+                cur ^= 1;
+                gload(t + 3, SetTag<1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                compute();
+                __builtin_amdgcn_sched_barrier(0);
+                lds_store(cur ^ 1, SetTag<0>{});
+                __syncthreads();
+                cur ^= 1;
+            }
+            if (has_next) {
+                setup_tile(next);
+                gload(0, SetTag<0>{});
+            }
+            compute();
+            lds_store(cur ^ 1, SetTag<1>{});
             __syncthreads();
             cur ^= 1;
+            if (has_next) gload(1, SetTag<1>{});
+            compute();
+            __syncthreads();
+        } else {
+            for (int t = 0; t < nk; ++t) {
+                const bool more = (t + 1) < nk;
+                if (more) {
+                    gload(t + 1, SetTag<0>{});
+                } else if (has_next) {   // prefetch the next tile's first slice; it lands during the epilogue
+                    setup_tile(next);
+                    gload(0, SetTag<0>{});
+                }
+                compute();
+                if (more) lds_store(cur ^ 1, SetTag<0>{});
+                __syncthreads();
+                cur ^= 1;
+            }
         }
 
         // ---- epilogue: accumulators -> LDS (row-major tile) -> 16-B channel-contiguous stores ----
@@ -363,12 +417,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // `cached` is a per-instantiation static owned by the caller (the value is idempotent, so a race between
 // host threads is benign).
 template <typename K>
-static int persistent_grid(K kernel, int nblk, int& cached) {
+static int persistent_grid(K kernel, int nblk, int& cached, int threads) {
     if (cached == 0) {
         int dev = 0, cus = 256, per_cu = 2;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         (void)hipGetLastError();
         cached = cus * per_cu;
     }
@@ -376,8 +430,12 @@ static int persistent_grid(K kernel, int nblk, int& cached) {
     return cached & ~7;                // several tiles per workgroup: the stride must keep tile % 8 fixed
 }
 
-template <int BM, int BN, int WM, int WN, int KSPLIT, int KU = 1, bool VEC = true>
+template <int BM, int BN, int WM, int WN, int KSPLIT, int KU = 1, bool VEC = true, bool PF2 = false>
 static int launch_cfg(ConvParams& p, hipStream_t st) {
+    if (PF2 && (((p.K + BK * KSPLIT * KU - 1) / (BK * KSPLIT * KU)) & 1)) {
+        set_error("conv_igemm: this tile configuration needs an even number of K steps");
+        return ICAP_ERR_ARG;
+    }
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const long long blocks = (long long)tiles_m * p.tiles_n;
@@ -387,12 +445,12 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
     }
     p.nblk = (int)blocks;
     const bool one = (p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0);
-    const dim3 block(256);
+    const dim3 block(64 * WM * WN * KSPLIT);
 #define ICAP_LAUNCH(O_, G_)                                                                          \
     do {                                                                                             \
         static int cached = 0;                                                                       \
-        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC>;                               \
-        hipLaunchKernelGGL(kern, dim3((unsigned)persistent_grid(kern, p.nblk, cached)), block, 0, st, p); \
+        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC, PF2>;                               \
+        hipLaunchKernelGGL(kern, dim3((unsigned)persistent_grid(kern, p.nblk, cached, (int)block.x)), block, 0, st, p); \
     } while (0)
     if (one && p.gate) ICAP_LAUNCH(true, true);
     else if (one) ICAP_LAUNCH(true, false);
@@ -425,6 +483,17 @@ static const TileCfg kCfgs[] = {
     {128, 64, 1, launch_cfg<128, 64, 2, 2, 1, 2>},  // 13
     {128, 128, 1, launch_cfg<128, 128, 2, 2, 1, 2>},// 14
     {64, 32, 2, launch_cfg<64, 32, 2, 1, 2, 2>},    // 15: 2 waves over rows x 2 over K
+    // 8- and 16-wave workgroups: the K range of every step is split over 2 or 4 waves per output block, so a
+    // problem with fewer tiles than the chip has CUs still keeps 2-4 waves on every SIMD of the CUs it uses.
+    {64, 64, 2, launch_cfg<64, 64, 2, 2, 2, 1>},    // 16
+    {64, 64, 2, launch_cfg<64, 64, 2, 2, 2, 2>},    // 17
+    {64, 64, 4, launch_cfg<64, 64, 2, 2, 4, 1>},    // 18
+    {128, 64, 2, launch_cfg<128, 64, 2, 2, 2, 2>},  // 19
+    {32, 64, 4, launch_cfg<32, 64, 1, 2, 4, 2>},    // 20
+    {32, 32, 8, launch_cfg<32, 32, 1, 1, 8, 1>},    // 21
+    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 2, true, true>},    // 22: two K slices in flight (even step counts only)
+    {32, 32, 4, launch_cfg<32, 32, 1, 1, 4, 1, true, true>},    // 23
+    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 1, true, true>},    // 24
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -495,6 +564,12 @@ int conv_igemm_f32(const float* x, const float* w, const float* scale, const flo
         if (it != g_tuned.end()) cfg = it->second;
     }
     if (cfg < 0) cfg = heuristic_cfg(p.M, Cout, p.K);
+    // tuning experiments only: ICAP_FORCE_CFG=<index> overrides the choice for every call
+    static const int forced = [] { const char* e = getenv("ICAP_FORCE_CFG"); return e ? atoi(e) : -1; }();
+    if (forced >= 0 && forced < kNumCfgs) {
+        ConvParams pf = p;
+        if (kCfgs[forced].fn(pf, st) == ICAP_OK) return ICAP_OK;   // a configuration that rejects the shape falls through
+    }
     return kCfgs[cfg].fn(p, st);
 }
 
@@ -569,6 +644,7 @@ int linear_argmax_f32(const float* x, const float* w, const float* scale, const 
     p.y = y;
     p.amax_val = part_val;
     p.amax_idx = part_idx;
+    if ((((K + BK - 1) / BK) & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, true>(p, st);
     return launch_cfg<64, 64, 2, 2, 1, 2>(p, st);
 }
 

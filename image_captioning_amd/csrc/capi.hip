@@ -50,6 +50,11 @@ int lstm_cell_f32(const float*, const float*, const float*, const float*, const 
 int gru_cell_f32(const float*, const float*, const float*, const float*, const float*, int, const float*, float*, int, int,
                  int, hipStream_t);
 
+int ce_loss_fwd_f32(const float*, int, int, int, const long long*, int, int, long long, int, float*, float*, float*, hipStream_t);
+int ce_loss_bwd_f32(const float*, int, int, int, const long long*, int, int, long long, const float*, const float*, const float*,
+                    float*, int, hipStream_t);
+int adamw_f32(float*, const float*, float*, float*, long long, float, float, float, float, float, int, float, hipStream_t);
+
 static inline long long align4(long long n) { return (n + 3) & ~3LL; }
 
 #define ICAP_TRY(expr)            \
@@ -343,6 +348,24 @@ int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC
         cur ^= 1;
     }
     return argmax_finalize_f32(pv, pi, P, ids + (steps - 1), steps, nullptr, nullptr, nullptr, 0, 0, NB, st);
+}
+
+// ------------------------------------------------------------------ training step
+int icap_ce_loss_fwd_f32(const float* logits, int ld, int group_rows, int group_stride, const long long* targets, int R,
+                         int V, long long ignore_index, int mean_over_valid, float* row_loss, float* row_lse, float* out,
+                         void* stream) {
+    return ce_loss_fwd_f32(logits, ld, group_rows, group_stride, targets, R, V, ignore_index, mean_over_valid, row_loss, row_lse, out, (hipStream_t)stream);
+}
+
+int icap_ce_loss_bwd_f32(const float* logits, int ld, int group_rows, int group_stride, const long long* targets, int R,
+                         int V, long long ignore_index, const float* row_lse, const float* meta, const float* grad_out,
+                         float* dlogits, int ldd, void* stream) {
+    return ce_loss_bwd_f32(logits, ld, group_rows, group_stride, targets, R, V, ignore_index, row_lse, meta, grad_out, dlogits, ldd, (hipStream_t)stream);
+}
+
+int icap_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float grad_scale, void* stream) {
+    return adamw_f32(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);
 }
 
 }  // extern "C"

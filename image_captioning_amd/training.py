@@ -1,0 +1,290 @@
+"""Training-step pieces: the reference's two masked cross-entropy losses, AdamW and the
+data-parallel gradient exchange.
+
+* ``compute_loss(predictions, targets, padding_idx)`` - data.py:244-252 / datachar.py:234-242.
+* ``CrossEntropyLoss(ignore_index=pad)`` - the criterion of seq2seqbasic.py:204,219.
+* ``AdamW`` - torch.optim.AdamW as configured at transformer_word_level_bahdnau.py:191,
+  transformer_word_level.py:138, transformercharmiguel.py:140 and seq2seqbasic.py:205-210:
+  every parameter of the model lives in ONE flat fp32 buffer (parameter ``.data`` and
+  ``.grad`` are views into flat buffers), so the update is a single kernel launch and the
+  gradient exchange works on contiguous slices.
+* ``GradientReducer`` - data-parallel training across one process per GPU: bucketed
+  all-reduce (RCCL through ``torch.distributed``; gloo on CPU tensors in tests) of the flat
+  gradient buffer, launched per bucket as soon as backward has produced every gradient in it.
+
+The loss and the optimizer arithmetic run in ``libicap_hip.so``; torch supplies memory,
+the autograd graph and the process group.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as N
+from .ops import _ck, _stream
+
+
+# ---------------------------------------------------------------------------- losses
+def _row_view(pred: torch.Tensor):
+    """(base tensor pointer info) of a [..., V] logits tensor whose rows are either contiguous or the
+    first rows of equally sized groups (a [B, T-1, V] slice of a contiguous [B, T, V] tensor)."""
+    if pred.dim() < 2 or pred.stride(-1) != 1:
+        raise N.IcapError("loss: logits need a contiguous last dimension")
+    V = pred.size(-1)
+    if pred.dim() == 2:
+        if pred.stride(0) < V:
+            raise N.IcapError("loss: overlapping logits rows")
+        return pred.size(0), V, pred.stride(0), pred.size(0), pred.size(0)
+    if pred.dim() == 3:
+        B, T1, _ = pred.shape
+        ld = pred.stride(1) if T1 > 1 else V
+        if ld < V or (B > 1 and pred.stride(0) % ld):
+            raise N.IcapError("loss: unsupported logits strides")
+        gs = pred.stride(0) // ld if B > 1 else T1
+        if gs < T1:
+            raise N.IcapError("loss: unsupported logits strides")
+        return B * T1, V, ld, T1, gs
+    raise N.IcapError("loss: logits must be [R, V] or [B, T, V]")
+
+
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, targets, ignore_index, mean_over_valid):
+        if not pred.is_cuda or pred.dtype != torch.float32:
+            raise N.IcapError("loss: logits must be an fp32 tensor on the HIP device (no CPU path)")
+        R, V, ld, gr, gs = _row_view(pred)
+        tg = targets.reshape(-1)
+        if tg.numel() != R or tg.dtype != torch.int64 or not tg.is_cuda:
+            raise N.IcapError("loss: targets must be int64 on the device, one per logits row")
+        tg = tg.contiguous()
+        dev = pred.device
+        row_loss = torch.empty(R, device=dev, dtype=torch.float32)
+        row_lse = torch.empty(R, device=dev, dtype=torch.float32)
+        out = torch.empty(2, device=dev, dtype=torch.float32)
+        N.check(N.load().icap_ce_loss_fwd_f32(pred.data_ptr(), ld, gr, gs, tg.data_ptr(), R, V, int(ignore_index),
+                                              int(mean_over_valid), row_loss.data_ptr(), row_lse.data_ptr(),
+                                              out.data_ptr(), _stream()), "ce_loss_fwd")
+        ctx.save_for_backward(pred, tg, row_lse, out)
+        ctx.geom = (R, V, ld, gr, gs, int(ignore_index))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pred, tg, row_lse, out = ctx.saved_tensors
+        R, V, ld, gr, gs, ignore = ctx.geom
+        # the gradient has the shape of `pred`; laid out densely, rows addressed as groups of gr
+        dl = torch.empty(pred.shape, device=pred.device, dtype=torch.float32)
+        g = grad_out.reshape(1).contiguous().float()
+        N.check(N.load().icap_ce_loss_bwd_f32(pred.data_ptr(), ld, gr, gs, tg.data_ptr(), R, V, ignore, row_lse.data_ptr(),
+                                              out.data_ptr(), g.data_ptr(), dl.data_ptr(), V, _stream()), "ce_loss_bwd")
+        return dl, None, None, None
+
+
+def compute_loss(predictions: torch.Tensor, targets: torch.Tensor, padding_idx: int) -> torch.Tensor:
+    """data.py:244-252: CE per position, pad positions zeroed, mean over ALL positions (pads in the denominator)."""
+    return _MaskedCE.apply(predictions, targets, padding_idx, False)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """nn.CrossEntropyLoss(ignore_index=...) as used at seq2seqbasic.py:204: mean over non-ignored rows."""
+
+    def __init__(self, ignore_index: int = -100):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, outputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        return _MaskedCE.apply(outputs, targets, self.ignore_index, True)
+
+
+# ---------------------------------------------------------------------------- optimizer
+class FlatParameters:
+    """Moves the trainable parameters of a model into ONE flat fp32 tensor.
+
+    ``param.data`` becomes a view into ``flat_p`` (values kept) and ``param.grad`` a view into ``flat_g``, so
+    backward accumulates straight into the flat gradient, clearing gradients is one memset, the optimizer
+    update is one kernel launch and the data-parallel exchange works on contiguous slices.  Pure bookkeeping:
+    works on any device.  ``touched[i]`` records whether backward produced a gradient for parameter i since the
+    last ``zero_grad`` (torch's optimizers skip parameters whose ``.grad`` is None; the reference's models carry
+    parameters that never get one, e.g. the unused self-attention of the word-level decoder).
+    """
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("fp32 parameters on one device required")
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4          # every parameter starts 16-byte aligned
+        self.n = n
+        self.flat_p = torch.zeros(n, device=dev)
+        self.flat_g = torch.zeros(n, device=dev)
+        self.touched = [False] * len(self.params)
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+                p.register_post_accumulate_grad_hook(self._mark(i))
+        self.grad_scale = 1.0
+
+    def _mark(self, i):
+        def hook(_p):
+            self.touched[i] = True
+        return hook
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        self.flat_g.zero_()
+        self.touched = [False] * len(self.params)
+        for p, o in zip(self.params, self.offsets):   # re-attach views a caller may have dropped
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def touched_runs(self, keys=None):
+        """Maximal [lo, hi) slices of the flat buffer covering consecutive parameters that received a gradient
+        (and, with `keys`, share the same key); returns (lo, hi) or (lo, hi, key) tuples."""
+        runs, lo, hi, key = [], None, None, None
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            end = o + (p.numel() + 3) // 4 * 4
+            k = keys[i] if keys is not None else None
+            if self.touched[i] and lo is not None and k == key:
+                hi = end
+                continue
+            if lo is not None:
+                runs.append((lo, hi) if keys is None else (lo, hi, key))
+                lo = None
+            if self.touched[i]:
+                lo, hi, key = o, end, k
+        if lo is not None:
+            runs.append((lo, hi) if keys is None else (lo, hi, key))
+        return runs
+
+
+class AdamW:
+    """torch.optim.AdamW(params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2) over ``FlatParameters``.
+
+    ``step`` launches ``icap_adamw_f32`` once per run of parameters that received a gradient (normally one or
+    two launches); parameters without a gradient are left untouched and their own step count (which sets the
+    bias correction) does not advance, as in torch.
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.flat = params if isinstance(params, FlatParameters) else FlatParameters(params)
+        if self.flat.flat_p.device.type != "cuda":
+            raise N.IcapError("AdamW: parameters must live on the HIP device (no CPU path)")
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.m = torch.zeros_like(self.flat.flat_p)
+        self.v = torch.zeros_like(self.flat.flat_p)
+        self.steps = 0
+        self.param_steps = [0] * len(self.flat.params)
+
+    @property
+    def params(self):
+        return self.flat.params
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        self.flat.zero_grad(set_to_none)
+
+    def step(self) -> None:
+        self.steps += 1
+        f = self.flat
+        lib = N.load()
+        self.param_steps = [s + 1 if t else s for s, t in zip(self.param_steps, f.touched)]
+        for lo, hi, step in f.touched_runs(self.param_steps):
+            N.check(lib.icap_adamw_f32(f.flat_p.data_ptr() + 4 * lo, f.flat_g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
+                                       self.v.data_ptr() + 4 * lo, hi - lo, self.lr, self.betas[0], self.betas[1], self.eps,
+                                       self.weight_decay, step, float(f.grad_scale), _stream()), "adamw")
+
+    def state_dict(self):
+        return {"step": self.steps, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr, "betas": self.betas,
+                "eps": self.eps, "weight_decay": self.weight_decay}
+
+
+# ---------------------------------------------------------------------------- data-parallel gradient exchange
+class GradientReducer:
+    """Sums the flat gradient buffer of ``FlatParameters`` (or of an ``AdamW``) across the ranks of a process
+    group in buckets.
+
+    One process per GPU; every rank computes the reference's loss on its own local batch, the gradients are
+    summed and divided by the world size (the optimizer applies the 1/world factor through ``grad_scale``), i.e.
+    the mean of the per-rank mean losses.  Buckets are contiguous slices of the flat gradient, filled in reverse
+    parameter order by backward; ``bucket_ready`` hooks launch the all-reduce of a bucket on a side stream as
+    soon as its last gradient has been accumulated, overlapping communication with the rest of backward.
+    """
+
+    def __init__(self, flat, group=None, bucket_mb: float = 16.0, overlap: bool = True):
+        import torch.distributed as dist
+        self.dist = dist
+        optimizer = flat.flat if isinstance(flat, AdamW) else flat
+        self.opt = optimizer
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        optimizer.grad_scale = 1.0 / self.world
+        per = max(4, int(bucket_mb * (1 << 20) / 4) // 4 * 4)
+        # buckets in reverse parameter order: the last parameters get their gradients first
+        self.buckets = []          # (lo, hi) float offsets
+        self.bucket_of = {}
+        hi = optimizer.n
+        cur_lo = hi
+        idxs = []
+        for i in reversed(range(len(optimizer.params))):
+            cur_lo = optimizer.offsets[i]
+            idxs.append(i)
+            if hi - cur_lo >= per or i == 0:
+                b = len(self.buckets)
+                self.buckets.append((cur_lo, hi))
+                for j in idxs:
+                    self.bucket_of[j] = b
+                idxs, hi = [], cur_lo
+        self.pending = [0] * len(self.buckets)
+        self.counts = [0] * len(self.buckets)
+        for j, b in self.bucket_of.items():
+            self.counts[b] += 1
+        self.handles = []
+        self.overlap = overlap and self.world > 1
+        self.comm_stream = torch.cuda.Stream() if (self.overlap and optimizer.flat_g.is_cuda) else None
+        self.launched = [False] * len(self.buckets)
+        if self.overlap:
+            for i, p in enumerate(optimizer.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_param):
+            b = self.bucket_of[i]
+            self.pending[b] += 1
+            if self.pending[b] == self.counts[b]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        lo, hi = self.buckets[b]
+        t = self.opt.flat_g[lo:hi]
+        self.launched[b] = True
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.handles.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.handles.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def prepare(self):
+        """Call before backward of every step."""
+        self.pending = [0] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+
+    def finish(self):
+        """Call after backward: reduces whatever the hooks did not (parameters without gradient this step,
+        or overlap disabled) and waits for all buckets."""
+        if self.world == 1:
+            return
+        for b in range(len(self.buckets)):
+            if not self.launched[b]:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.handles = []

@@ -229,6 +229,37 @@ int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC
                         long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream);
 long long icap_greedy_bah_ws_floats(int NB, int E, int ENC, int H, int V);
 
+/* ------------------------------------------------------------------ training step: losses and optimizer */
+
+/* Masked cross entropy over R rows of V logits.  Row r of the logits lives at
+ * ((r / group_rows) * group_stride + r % group_rows) * ld floats, which addresses
+ * predictions[:, :-1] of a [B][T][V] tensor in place (group_rows = T-1,
+ * group_stride = T); a plain [R][V] matrix is group_rows = group_stride = R.
+ * mean_over_valid = 0: sum over non-ignored rows / R, pads stay in the denominator
+ *   (compute_loss, data.py:244-252, datachar.py:234-242);
+ * mean_over_valid = 1: sum / number of non-ignored rows
+ *   (nn.CrossEntropyLoss(ignore_index=PAD), seq2seqbasic.py:204,219).
+ * row_loss, row_lse [R] are kept for the backward pass; out[0] = loss, out[1] = the
+ * per-row scale that was applied. */
+int icap_ce_loss_fwd_f32(const float* logits, int ld, int group_rows, int group_stride, const long long* targets,
+                         int R, int V, long long ignore_index, int mean_over_valid, float* row_loss, float* row_lse,
+                         float* out, void* stream);
+
+/* dlogits = d loss / d logits * grad_out[0] (device scalar) as a dense [R][ldd]
+ * matrix (the logits keep the grouped addressing); ignored rows get zeros.  loss.backward() of the two losses
+ * above (transformer_word_level_bahdnau.py:230-232, seq2seqbasic.py:219-221). */
+int icap_ce_loss_bwd_f32(const float* logits, int ld, int group_rows, int group_stride, const long long* targets,
+                         int R, int V, long long ignore_index, const float* row_lse, const float* meta,
+                         const float* grad_out, float* dlogits, int ldd, void* stream);
+
+/* One AdamW step over a flat buffer of n floats (n % 4 == 0), torch.optim.AdamW
+ * update order; step counts from 1; every gradient is multiplied by grad_scale first
+ * (1/world_size after a summing all-reduce).  optimizer.step() of
+ * transformer_word_level_bahdnau.py:191,233; transformer_word_level.py:138;
+ * seq2seqbasic.py:205-210,222. */
+int icap_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

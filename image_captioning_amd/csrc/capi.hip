@@ -55,6 +55,27 @@ int ce_loss_bwd_f32(const float*, int, int, int, const long long*, int, int, lon
                     float*, int, hipStream_t);
 int adamw_f32(float*, const float*, float*, float*, long long, float, float, float, float, float, int, float, hipStream_t);
 
+int gemm_bwd_f32(const float*, int, int, const float*, int, float*, int, int, int, int, int, float*, hipStream_t);
+long long gemm_bwd_ws_floats(int, int, int, int);
+int col_reduce_f32(int, const float*, int, const float*, int, const float*, const float*, const float*, const float*, const float*,
+                   const float*, int, int, int, float, int, float*, float*, float*, hipStream_t);
+long long col_reduce_ws_floats(int, int);
+int bn_finalize_f32(const float*, const float*, const float*, const float*, float, float, int, int, float*, float*, float*, float*,
+                    float*, hipStream_t);
+int scale_bias_act_f32(const float*, int, const float*, const float*, const float*, int, int, int, int, float*, int, hipStream_t);
+int bn_act_bwd_f32(const float*, int, const float*, int, const float*, const float*, const float*, const float*, const float*,
+                   const float*, int, int, int, float*, int, hipStream_t);
+int axpby_f32(const float*, float, float, float*, long long, hipStream_t);
+int dropout_f32(const float*, float, unsigned long long, unsigned long long, long long, long long, float*, float*, hipStream_t);
+int mul_mask_f32(const float*, const float*, long long, const float*, long long, float*, hipStream_t);
+int ln_train_fwd_f32(const float*, const float*, const float*, const float*, float, float, int, int, float*, float*, float*, float*,
+                     hipStream_t);
+int ln_bwd_f32(const float*, const float*, const float*, const float*, const float*, float, int, int, float*, hipStream_t);
+int lstm_bwd_f32(const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, hipStream_t);
+int att_bwd_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, float*,
+                float*, float*, float*, float*, float*, hipStream_t);
+int embedding_bwd_f32(const long long*, const float*, int, int, int, int, float*, hipStream_t);
+
 static inline long long align4(long long n) { return (n + 3) & ~3LL; }
 
 #define ICAP_TRY(expr)            \
@@ -366,6 +387,73 @@ int icap_ce_loss_bwd_f32(const float* logits, int ld, int group_rows, int group_
 int icap_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, float grad_scale, void* stream) {
     return adamw_f32(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);
+}
+
+int icap_gemm_bwd_f32(const float* a, int lda, int a_kmajor, const float* b, int ldb, float* c, int ldc, int M, int N, int K,
+                      int accumulate, float* ws, void* stream) {
+    return gemm_bwd_f32(a, lda, a_kmajor, b, ldb, c, ldc, M, N, K, accumulate, ws, (hipStream_t)stream);
+}
+long long icap_gemm_bwd_ws_floats(int M, int N, int K, int accumulate) { return gemm_bwd_ws_floats(M, N, K, accumulate); }
+
+int icap_col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, const float* v1, const float* v2,
+                        const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C, float scale,
+                        int accumulate, float* out1, float* out2, float* ws, void* stream) {
+    return col_reduce_f32(mode, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, scale, accumulate, out1, out2, ws, (hipStream_t)stream);
+}
+long long icap_col_reduce_ws_floats(int M, int C) { return col_reduce_ws_floats(M, C); }
+
+int icap_bn_finalize_f32(const float* mean, const float* sqdev, const float* gamma, const float* beta, float eps, float momentum,
+                         int M, int C, float* rstd, float* s, float* b, float* run_mean, float* run_var, void* stream) {
+    return bn_finalize_f32(mean, sqdev, gamma, beta, eps, momentum, M, C, rstd, s, b, run_mean, run_var, (hipStream_t)stream);
+}
+
+int icap_scale_bias_act_f32(const float* x, int ldx, const float* s, const float* b, const float* res, int ldr, int act, int M,
+                            int C, float* y, int ldy, void* stream) {
+    return scale_bias_act_f32(x, ldx, s, b, res, ldr, act, M, C, y, ldy, (hipStream_t)stream);
+}
+
+int icap_bn_act_bwd_f32(const float* dy, int ldd, const float* x, int ldx, const float* s, const float* b, const float* mean,
+                        const float* rstd, const float* dgamma, const float* dbeta, int act, int M, int C, float* dx, int ldo,
+                        void* stream) {
+    return bn_act_bwd_f32(dy, ldd, x, ldx, s, b, mean, rstd, dgamma, dbeta, act, M, C, dx, ldo, (hipStream_t)stream);
+}
+
+int icap_axpby_f32(const float* x, float alpha, float beta, float* y, long long n, void* stream) {
+    return axpby_f32(x, alpha, beta, y, n, (hipStream_t)stream);
+}
+
+int icap_dropout_f32(const float* x, float p, unsigned long long seed, unsigned long long offset, long long n, long long group,
+                     float* y, float* mask, void* stream) {
+    return dropout_f32(x, p, seed, offset, n, group, y, mask, (hipStream_t)stream);
+}
+
+int icap_mul_mask_f32(const float* x, const float* mask, long long group, const float* add, long long n, float* y, void* stream) {
+    return mul_mask_f32(x, mask, group, add, n, y, (hipStream_t)stream);
+}
+
+int icap_ln_train_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps, float pre_scale,
+                          int R, int E, float* y, float* xs, float* mean, float* rstd, void* stream) {
+    return ln_train_fwd_f32(x, res, gamma, beta, eps, pre_scale, R, E, y, xs, mean, rstd, (hipStream_t)stream);
+}
+
+int icap_ln_bwd_f32(const float* dy, const float* xs, const float* gamma, const float* mean, const float* rstd, float post_scale,
+                    int R, int E, float* dx, void* stream) {
+    return ln_bwd_f32(dy, xs, gamma, mean, rstd, post_scale, R, E, dx, (hipStream_t)stream);
+}
+
+int icap_lstm_bwd_f32(const float* gates, const float* c_in, const float* c_out, const float* dh, const float* dc, int B, int H,
+                      float* dgates, float* dc_prev, void* stream) {
+    return lstm_bwd_f32(gates, c_in, c_out, dh, dc, B, H, dgates, dc_prev, (hipStream_t)stream);
+}
+
+int icap_att_bwd_f32(const float* u, const float* w, const float* a_w, const float* alpha, const float* feat, const float* dctx,
+                     int B, int A, int E, int accumulate, float* dscore, float* dw, float* da_part, float* dab_part, float* du,
+                     float* dfeat, void* stream) {
+    return att_bwd_f32(u, w, a_w, alpha, feat, dctx, B, A, E, accumulate, dscore, dw, da_part, dab_part, du, dfeat, (hipStream_t)stream);
+}
+
+int icap_embedding_bwd_f32(const long long* idx, const float* dy, int ldd, int P, int E, int V, float* dtable, void* stream) {
+    return embedding_bwd_f32(idx, dy, ldd, P, E, V, dtable, (hipStream_t)stream);
 }
 
 }  // extern "C"

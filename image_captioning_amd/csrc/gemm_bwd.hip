@@ -1,0 +1,200 @@
+// GEMMs of the backward pass, fp32 on v_mfma_f32_32x32x2_f32.
+//
+// The forward kernel (conv_igemm.hip) multiplies two operands whose rows are contiguous
+// along the contraction index ("NT": Y = X W^T).  Back-propagation needs the other two
+// forms, and transposing activations first would cost an extra pass over HBM:
+//   NN  dX[M][N] = dY[M][K] . W[K][N]        A rows contiguous along k, B rows along n
+//   TN  dW[M][N] = dY[K][M]^T . X[K][N]      both operands stored k-major; the contraction
+//                                            runs over rows (batch x positions), often 10^5+
+// An operand stored k-major is staged in LDS as [k][m] with 16-byte loads along m and
+// read back one float per lane (lane = output row / column: consecutive addresses, no
+// bank conflicts); an operand stored k-contiguous is staged as padded rows [m][k] and
+// read back 16 bytes per lane.
+//
+// TN problems have few output tiles and a very long contraction, so the contraction is
+// split over gridDim.z workgroups; each writes its partial tile to a workspace and a
+// second kernel adds the partials in a fixed order (deterministic, no atomics).
+#include "common.hpp"
+
+namespace icap {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+    const float* a;
+    const float* b;
+    float* c;          // [M][ldc] result, or the partial workspace [splits][M][N] when splits > 1
+    int M, N, K;
+    int lda, ldb, ldc;
+    int splits, k_per_split;
+};
+
+constexpr int GB_BM = 64, GB_BN = 64, GB_BK = 16;
+constexpr int GB_LDK = GB_BK + 4;   // padded row of a k-contiguous operand tile
+constexpr int GB_LDM = GB_BM + 4;   // padded row of a k-major operand tile (keeps 16-byte alignment)
+
+// A_KM: A is stored [K][M] (k-major) instead of [M][K].  B is always [K][N].
+template <bool A_KM>
+__global__ __launch_bounds__(256) void gemm_bwd_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float As[2][A_KM ? GB_BK * GB_LDM : GB_BM * GB_LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GB_BK * GB_LDM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * GB_BM, n0 = blockIdx.x * GB_BN;
+    const int k_lo = blockIdx.z * p.k_per_split;
+    const int k_hi = min(p.K, k_lo + p.k_per_split);
+    const int nk = (k_hi - k_lo + GB_BK - 1) / GB_BK;
+
+    // staging coordinates: one float4 per thread and operand per K step
+    //   k-major tile [16 k][64 m]: thread -> (k = tid / 16, m4 = tid % 16)
+    //   k-contiguous tile [64 m][16 k]: thread -> (m = tid / 4, k4 = tid % 4)
+    const int km_k = tid >> 4, km_c = (tid & 15) << 2;
+    const int kc_m = tid >> 2, kc_k = (tid & 3) << 2;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // 16-byte load with element-wise bounds along the contiguous index; rows and columns beyond the
+    // matrix read a valid address and are zeroed
+    auto load4 = [&](const float* base, int ld, int row, int row_lim, int col, int col_lim) -> float4 {
+        const bool row_ok = row < row_lim;
+        const float* src = base + (size_t)(row_ok ? row : 0) * ld;
+        if (col + 3 < col_lim && (ld & 3) == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(src + col);
+            return row_ok ? v : z;
+        }
+        float4 v = z;
+        if (row_ok) {
+            if (col < col_lim) v.x = src[col];
+            if (col + 1 < col_lim) v.y = src[col + 1];
+            if (col + 2 < col_lim) v.z = src[col + 2];
+            if (col + 3 < col_lim) v.w = src[col + 3];
+        }
+        return v;
+    };
+    float4 ra, rb;
+    auto gload = [&](int t) {
+        const int kb = k_lo + t * GB_BK;
+        if (A_KM) ra = load4(p.a, p.lda, kb + km_k, k_hi, m0 + km_c, p.M);
+        else ra = load4(p.a, p.lda, m0 + kc_m, p.M, kb + kc_k, k_hi);
+        rb = load4(p.b, p.ldb, kb + km_k, k_hi, n0 + km_c, p.N);
+    };
+    auto lds_store = [&](int buf) {
+        if (A_KM) *reinterpret_cast<float4*>(&As[buf][km_k * GB_LDM + km_c]) = ra;
+        else *reinterpret_cast<float4*>(&As[buf][kc_m * GB_LDK + kc_k]) = ra;
+        *reinterpret_cast<float4*>(&Bs[buf][km_k * GB_LDM + km_c]) = rb;
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    if (nk > 0) {
+        gload(0);
+        lds_store(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nk; ++t) {
+        const bool more = t + 1 < nk;
+        if (more) gload(t + 1);
+        float af[8], bf[8];
+        if (A_KM) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) af[s] = As[cur][(2 * s + lh) * GB_LDM + wm * 32 + lr];
+        } else {
+            // lane (lr, lh) takes k = 8*lh + s for step s; B below follows the same assignment
+            const float* src = &As[cur][(wm * 32 + lr) * GB_LDK + 8 * lh];
+            const float4 v0 = *reinterpret_cast<const float4*>(src);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+            af[0] = v0.x; af[1] = v0.y; af[2] = v0.z; af[3] = v0.w;
+            af[4] = v1.x; af[5] = v1.y; af[6] = v1.z; af[7] = v1.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = A_KM ? (2 * s + lh) : (8 * lh + s);
+            bf[s] = Bs[cur][k * GB_LDM + wn * 32 + lr];
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+        if (more) lds_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // a lane holds column n = lr and rows (e&3) + 8*(e>>2) + 4*lh of the wave's 32x32 block
+    float* c = p.c + (p.splits > 1 ? (size_t)blockIdx.z * p.M * p.N : 0);
+    const int ldc = p.splits > 1 ? p.N : p.ldc;
+    const int n = n0 + wn * 32 + lr;
+    if (n < p.N) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (m < p.M) c[(size_t)m * ldc + n] = acc[e];
+        }
+    }
+}
+
+// c[m][n] = (accumulate ? c[m][n] : 0) + sum_s part[s][m][n], fixed order
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N,
+                                                                 float* __restrict__ c, int ldc, int accumulate) {
+    const long long total = (long long)M * N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+        float s = accumulate ? c[(size_t)m * ldc + n] : 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(size_t)k * total + i];
+        c[(size_t)m * ldc + n] = s;
+    }
+}
+
+static int pick_splits(int M, int N, int K) {
+    const long long tiles = (long long)((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
+    if (tiles >= 512 || K <= 256) return 1;
+    long long s = (1024 + tiles - 1) / tiles;
+    const long long max_s = K / 128 > 0 ? K / 128 : 1;   // at least 128 contraction steps per split
+    if (s > max_s) s = max_s;
+    if (s > 256) s = 256;
+    return (int)(s < 1 ? 1 : s);
+}
+
+// floats of workspace gemm_bwd_f32 needs for this problem (0 when the contraction is not split and the result
+// is not accumulated onto C)
+long long gemm_bwd_ws_floats(int M, int N, int K, int accumulate) {
+    const int s = pick_splits(M, N, K);
+    return (s > 1 || accumulate) ? (long long)s * M * N : 0;
+}
+
+// C[M][N] (+)= op(A) . B with B stored [K][N]; op(A) = A stored [M][K] (a_kmajor = 0) or A stored [K][M] (1).
+int gemm_bwd_f32(const float* a, int lda, int a_kmajor, const float* b, int ldb, float* c, int ldc, int M, int N, int K,
+                 int accumulate, float* ws, hipStream_t st) {
+    if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || ldb < N || ldc < N || (a_kmajor ? lda < M : lda < K)) {
+        set_error("gemm_bwd: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (!aligned16(a) || !aligned16(b)) { set_error("gemm_bwd: operands must be 16-byte aligned"); return ICAP_ERR_ALIGN; }
+    int splits = pick_splits(M, N, K);
+    if (splits > 1 && !ws) { set_error("gemm_bwd: workspace required (gemm_bwd_ws_floats)"); return ICAP_ERR_ARG; }
+    GemmParams p{a, b, c, M, N, K, lda, ldb, ldc, splits, 0};
+    int kps = (K + splits - 1) / splits;
+    kps = (kps + GB_BK - 1) / GB_BK * GB_BK;
+    splits = (K + kps - 1) / kps;
+    p.splits = splits;
+    p.k_per_split = kps;
+    const bool direct = splits == 1 && !accumulate;
+    if (!direct) {
+        if (!ws && splits == 1) { set_error("gemm_bwd: accumulation needs a workspace of M*N floats"); return ICAP_ERR_ARG; }
+        p.c = ws;
+        if (splits == 1) { p.splits = 2; }   // route the single partial through the workspace layout [1][M][N]
+    }
+    const dim3 grid((N + GB_BN - 1) / GB_BN, (M + GB_BM - 1) / GB_BM, splits);
+    if (a_kmajor) hipLaunchKernelGGL(gemm_bwd_kernel<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_bwd_kernel<false>, grid, dim3(256), 0, st, p);
+    if (!direct) {
+        const long long total = (long long)M * N;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, splits, M, N, c, ldc, accumulate);
+    }
+    return launch_status("gemm_bwd");
+}
+
+}  // namespace icap

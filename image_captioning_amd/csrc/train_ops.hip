@@ -1,0 +1,484 @@
+// Row / column / element kernels of the training-mode forward and of the backward pass:
+// column reductions (bias gradients, BatchNorm statistics and gradients, LayerNorm
+// parameter gradients), BatchNorm and LayerNorm in training mode, dropout, activation
+// gradients, the LSTM cell gradient, the additive-attention gradient and the embedding
+// gradient.  All of them are bound by memory traffic; reductions run in a fixed order
+// (two passes, no atomics), so a training step is reproducible bit for bit.
+#include "common.hpp"
+
+namespace icap {
+
+// ---------------------------------------------------------------- column reductions
+// x, y: [M][C] row-major (row strides ldx / ldy).  A workgroup owns 64 columns and one chunk of
+// COL_ROWS rows; partial sums go to part[chunk][C] (two planes when the mode has two results) and
+// col_finish_kernel adds the chunks in order.
+constexpr int COL_ROWS = 512;
+
+enum ColMode : int {
+    COL_SUM = 0,        // s1 = sum a
+    COL_SQDEV = 1,      // s1 = sum (a - v1[c])^2                                (variance given the mean)
+    COL_BN_BWD = 2,     // s1 = sum g, s2 = sum g * (x - v1[c]) * v2[c]          (g = a * act'(x*v3[c] + v4[c]))
+    COL_LN_BWD = 3,     // s1 = sum a, s2 = sum a * (x - r1[r]) * r2[r]          (per-row mean / rstd)
+};
+
+__device__ __forceinline__ float act_grad(float z, int act) {
+    switch (act) {
+        case ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case ACT_SWISH: { const float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
+        case ACT_SIGMOID: { const float s = sigmoidf_(z); return s * (1.f - s); }
+        case ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
+        default: return 1.f;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, int lda, const float* __restrict__ x,
+                                                          int ldx, const float* __restrict__ v1, const float* __restrict__ v2,
+                                                          const float* __restrict__ v3, const float* __restrict__ v4,
+                                                          const float* __restrict__ r1, const float* __restrict__ r2, int act,
+                                                          int M, int C, float* __restrict__ part) {
+    __shared__ float red[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int chunk = blockIdx.y, nchunks = gridDim.y;
+    const int r_lo = chunk * COL_ROWS, r_hi = min(M, r_lo + COL_ROWS);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        float m = 0.f, rs = 0.f, sc = 0.f, bi = 0.f;
+        if (MODE == COL_SQDEV || MODE == COL_BN_BWD) m = v1[c];
+        if (MODE == COL_BN_BWD) { rs = v2[c]; sc = v3[c]; bi = v4[c]; }
+        for (int r = r_lo + ry; r < r_hi; r += 4) {
+            const float av = a[(size_t)r * lda + c];
+            if (MODE == COL_SUM) {
+                s1 += av;
+            } else if (MODE == COL_SQDEV) {
+                const float d = av - m;
+                s1 += d * d;
+            } else if (MODE == COL_BN_BWD) {
+                const float xv = x[(size_t)r * ldx + c];
+                const float g = av * act_grad(fmaf(xv, sc, bi), act);
+                s1 += g;
+                s2 += g * ((xv - m) * rs);
+            } else {
+                const float xv = x[(size_t)r * ldx + c];
+                s1 += av;
+                s2 += av * ((xv - r1[r]) * r2[r]);
+            }
+        }
+    }
+    red[0][ry][cx] = s1;
+    red[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        part[(size_t)chunk * C + c] = ((red[0][0][cx] + red[0][1][cx]) + red[0][2][cx]) + red[0][3][cx];
+        if (MODE >= COL_BN_BWD)
+            part[(size_t)(nchunks + chunk) * C + c] = ((red[1][0][cx] + red[1][1][cx]) + red[1][2][cx]) + red[1][3][cx];
+    }
+}
+
+// out1[c] = scale * sum_chunks part[chunk][c] (+ out1[c] when accumulate); same for the second plane
+__global__ __launch_bounds__(256) void col_finish_kernel(const float* __restrict__ part, int nchunks, int C, int planes,
+                                                         float scale, int accumulate, float* __restrict__ out1,
+                                                         float* __restrict__ out2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int pl = 0; pl < planes; ++pl) {
+        float s = 0.f;
+        for (int k = 0; k < nchunks; ++k) s += part[(size_t)(pl * nchunks + k) * C + c];
+        float* o = pl == 0 ? out1 : out2;
+        o[c] = (accumulate ? o[c] : 0.f) + s * scale;
+    }
+}
+
+long long col_reduce_ws_floats(int M, int C) { return 2LL * ((M + COL_ROWS - 1) / COL_ROWS) * C; }
+
+int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, const float* v1, const float* v2,
+                   const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C, float scale,
+                   int accumulate, float* out1, float* out2, float* ws, hipStream_t st) {
+    if (!a || !out1 || !ws || M <= 0 || C <= 0 || lda < C || mode < 0 || mode > 3) { set_error("col_reduce: bad arguments"); return ICAP_ERR_ARG; }
+    if (mode == COL_SQDEV && !v1) { set_error("col_reduce: mean required"); return ICAP_ERR_ARG; }
+    if (mode == COL_BN_BWD && (!x || !v1 || !v2 || !v3 || !v4 || !out2 || ldx < C)) { set_error("col_reduce: BatchNorm operands required"); return ICAP_ERR_ARG; }
+    if (mode == COL_LN_BWD && (!x || !r1 || !r2 || !out2 || ldx < C)) { set_error("col_reduce: LayerNorm operands required"); return ICAP_ERR_ARG; }
+    const int nchunks = (M + COL_ROWS - 1) / COL_ROWS;
+    const dim3 grid((C + 63) / 64, nchunks);
+    switch (mode) {
+        case COL_SUM: hipLaunchKernelGGL(col_partial_kernel<COL_SUM>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+        case COL_SQDEV: hipLaunchKernelGGL(col_partial_kernel<COL_SQDEV>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+        case COL_BN_BWD: hipLaunchKernelGGL(col_partial_kernel<COL_BN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+        default: hipLaunchKernelGGL(col_partial_kernel<COL_LN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+    }
+    hipLaunchKernelGGL(col_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, nchunks, C, mode >= COL_BN_BWD ? 2 : 1, scale, accumulate, out1, out2);
+    return launch_status("col_reduce");
+}
+
+// ---------------------------------------------------------------- BatchNorm (training mode)
+// From the batch mean and the summed squared deviations: rstd, the fused scale / bias of the
+// normalisation (y = x*s + b) and the running statistics update
+//   running = (1 - momentum) * running + momentum * batch   (variance: unbiased, n / (n - 1)).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ sqdev,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, int M, int C, float* __restrict__ rstd,
+                                                          float* __restrict__ s, float* __restrict__ b,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float var = sqdev[c] / (float)M;
+    const float r = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f;
+    rstd[c] = r;
+    s[c] = g * r;
+    b[c] = (beta ? beta[c] : 0.f) - mean[c] * g * r;
+    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
+    if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * (M > 1 ? sqdev[c] / (float)(M - 1) : var);
+}
+
+int bn_finalize_f32(const float* mean, const float* sqdev, const float* gamma, const float* beta, float eps, float momentum,
+                    int M, int C, float* rstd, float* s, float* b, float* run_mean, float* run_var, hipStream_t st) {
+    if (!mean || !sqdev || !rstd || !s || !b || M <= 0 || C <= 0) { set_error("bn_finalize: bad arguments"); return ICAP_ERR_ARG; }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, sqdev, gamma, beta, eps, momentum, M, C, rstd, s, b, run_mean, run_var);
+    return launch_status("bn_finalize");
+}
+
+// y[r][c] = act(x[r][c] * s[c] + b[c]) (+ res[r][c]); s, b may be null (1, 0)
+__global__ __launch_bounds__(256) void scale_bias_act_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ s,
+                                                             const float* __restrict__ b, const float* __restrict__ res,
+                                                             int ldr, int act, int M, int C, float* __restrict__ y, int ldy) {
+    const long long total = (long long)M * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / C), c = (int)(i - (long long)r * C);
+        float v = act_apply(fmaf(x[(size_t)r * ldx + c], s ? s[c] : 1.f, b ? b[c] : 0.f), act);
+        if (res) v += res[(size_t)r * ldr + c];
+        y[(size_t)r * ldy + c] = v;
+    }
+}
+
+int scale_bias_act_f32(const float* x, int ldx, const float* s, const float* b, const float* res, int ldr, int act, int M, int C,
+                       float* y, int ldy, hipStream_t st) {
+    if (!x || !y || M <= 0 || C <= 0 || ldx < C || ldy < C || (res && ldr < C)) { set_error("scale_bias_act: bad arguments"); return ICAP_ERR_ARG; }
+    long long blocks = ((long long)M * C + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, s, b, res, ldr, act, M, C, y, ldy);
+    return launch_status("scale_bias_act");
+}
+
+// BatchNorm + activation, gradient with respect to the input:
+//   g = dy * act'(x*s + b);  dx = s[c] * (g - dbeta[c]/M - xhat * dgamma[c]/M),  xhat = (x - mean[c]) * rstd[c]
+// With mean == null the layer is a plain per-channel affine + activation (eval-mode statistics): dx = s[c] * g.
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ s, const float* __restrict__ b,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                         int act, int M, int C, float* __restrict__ dx, int ldo) {
+    const long long total = (long long)M * C;
+    const float inv_m = 1.0f / (float)M;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / C), c = (int)(i - (long long)r * C);
+        const float xv = x[(size_t)r * ldx + c];
+        const float sc = s ? s[c] : 1.f;
+        float g = dy[(size_t)r * ldd + c] * act_grad(fmaf(xv, sc, b ? b[c] : 0.f), act);
+        if (mean) g = g - dbeta[c] * inv_m - (xv - mean[c]) * rstd[c] * dgamma[c] * inv_m;
+        dx[(size_t)r * ldo + c] = sc * g;
+    }
+}
+
+int bn_act_bwd_f32(const float* dy, int ldd, const float* x, int ldx, const float* s, const float* b, const float* mean,
+                   const float* rstd, const float* dgamma, const float* dbeta, int act, int M, int C, float* dx, int ldo,
+                   hipStream_t st) {
+    if (!dy || !x || !dx || M <= 0 || C <= 0 || ldd < C || ldx < C || ldo < C || (mean && (!rstd || !dgamma || !dbeta))) {
+        set_error("bn_act_bwd: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    long long blocks = ((long long)M * C + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma, dbeta, act, M, C, dx, ldo);
+    return launch_status("bn_act_bwd");
+}
+
+// ---------------------------------------------------------------- elementwise helpers
+// y = alpha * x + beta * y over n elements
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float alpha, float beta, float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = alpha * x[i] + (beta != 0.f ? beta * y[i] : 0.f);
+}
+
+int axpby_f32(const float* x, float alpha, float beta, float* y, long long n, hipStream_t st) {
+    if (!x || !y || n <= 0) { set_error("axpby: bad arguments"); return ICAP_ERR_ARG; }
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, alpha, beta, y, n);
+    return launch_status("axpby");
+}
+
+// Dropout with a counter-based generator: element i of call (seed, offset) keeps its value, scaled by 1/(1-p),
+// when hash(seed, offset + i) >= p.  mask[i] holds the factor that was applied (0 or 1/(1-p)), which is also the
+// gradient factor.  x may equal y.
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float p, unsigned long long seed,
+                                                      unsigned long long offset, long long n, long long group,
+                                                      float* __restrict__ y, float* __restrict__ mask) {
+    const float keep = 1.0f / (1.0f - p);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        // group > 1: one decision per group of consecutive elements (drop-connect: per sample)
+        const float f = uniform01(seed, offset + (unsigned long long)(i / group)) >= p ? keep : 0.f;
+        mask[group > 1 ? i / group : i] = f;
+        y[i] = x[i] * f;
+    }
+}
+
+int dropout_f32(const float* x, float p, unsigned long long seed, unsigned long long offset, long long n, long long group,
+                float* y, float* mask, hipStream_t st) {
+    if (!x || !y || !mask || n <= 0 || group <= 0 || !(p >= 0.f && p < 1.f)) { set_error("dropout: bad arguments"); return ICAP_ERR_ARG; }
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, p, seed, offset, n, group, y, mask);
+    return launch_status("dropout");
+}
+
+// y[i] = x[i] * mask[i / group] (+ add[i]): applies a stored dropout / drop-connect mask, forward or backward
+__global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask, long long group,
+                                                       const float* __restrict__ add, long long n, float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = x[i] * mask[i / group];
+        if (add) v += add[i];
+        y[i] = v;
+    }
+}
+
+int mul_mask_f32(const float* x, const float* mask, long long group, const float* add, long long n, float* y, hipStream_t st) {
+    if (!x || !mask || !y || n <= 0 || group <= 0) { set_error("mul_mask: bad arguments"); return ICAP_ERR_ARG; }
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mul_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, mask, group, add, n, y);
+    return launch_status("mul_mask");
+}
+
+// ---------------------------------------------------------------- LayerNorm (training): forward keeps mean / rstd
+// y = ((x (+ res)) * pre_scale - mean) * rstd * gamma + beta, one wave per row; xs (optional) receives the
+// normalised-input x (+ res) * pre_scale that the backward pass needs.
+__global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float pre_scale, int R, int E, float* __restrict__ y,
+                                                           float* __restrict__ xs, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const float* xr = x + (size_t)r * E;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        float t = xr[e];
+        if (res) t += res[(size_t)r * E + e];
+        s += t * pre_scale;
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        float t = xr[e];
+        if (res) t += res[(size_t)r * E + e];
+        const float d = t * pre_scale - mean;
+        q = fmaf(d, d, q);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
+    for (int e = lane; e < E; e += 64) {
+        float t = xr[e];
+        if (res) t += res[(size_t)r * E + e];
+        t *= pre_scale;
+        if (xs) xs[(size_t)r * E + e] = t;
+        y[(size_t)r * E + e] = (t - mean) * rstd * gamma[e] + beta[e];
+    }
+    if (lane == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
+}
+
+int ln_train_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps, float pre_scale, int R,
+                     int E, float* y, float* xs, float* mean, float* rstd, hipStream_t st) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || R <= 0 || E <= 0) { set_error("ln_train_fwd: bad arguments"); return ICAP_ERR_ARG; }
+    hipLaunchKernelGGL(ln_train_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, st, x, res, gamma, beta, eps, pre_scale, R, E, y, xs, mean, rstd);
+    return launch_status("ln_train_fwd");
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) * post_scale,  g = dy * gamma,  xhat = (xs - mean) * rstd
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xs,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float post_scale, int R, int E,
+                                                     float* __restrict__ dx) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const float m = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        const float g = dy[(size_t)r * E + e] * gamma[e];
+        s1 += g;
+        s2 += g * ((xs[(size_t)r * E + e] - m) * rs);
+    }
+    s1 = wave_sum(s1) / (float)E;
+    s2 = wave_sum(s2) / (float)E;
+    for (int e = lane; e < E; e += 64) {
+        const float g = dy[(size_t)r * E + e] * gamma[e];
+        const float xh = (xs[(size_t)r * E + e] - m) * rs;
+        dx[(size_t)r * E + e] = rs * (g - s1 - xh * s2) * post_scale;
+    }
+}
+
+int ln_bwd_f32(const float* dy, const float* xs, const float* gamma, const float* mean, const float* rstd, float post_scale, int R,
+               int E, float* dx, hipStream_t st) {
+    if (!dy || !xs || !gamma || !mean || !rstd || !dx || R <= 0 || E <= 0) { set_error("ln_bwd: bad arguments"); return ICAP_ERR_ARG; }
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, st, dy, xs, gamma, mean, rstd, post_scale, R, E, dx);
+    return launch_status("ln_bwd");
+}
+
+// ---------------------------------------------------------------- LSTM cell gradient
+// gates: pre-activations [B][4H] (i, f, g, o); given dh, dc (gradient flowing into c_out from the next step):
+//   do = dh * tanh(c_out);  dc_tot = dc + dh * o * (1 - tanh(c_out)^2)
+//   di = dc_tot * g;  df = dc_tot * c_in;  dg = dc_tot * i;  dc_prev = dc_tot * f
+// and the pre-activation gradients dgates = d* times the activation derivatives.
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_in,
+                                                       const float* __restrict__ c_out, const float* __restrict__ dh,
+                                                       const float* __restrict__ dc, int B, int H,
+                                                       float* __restrict__ dgates, float* __restrict__ dc_prev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    const float* g = gates + (size_t)b * 4 * H;
+    const float ig = sigmoidf_(g[j]), fg = sigmoidf_(g[H + j]), gg = tanhf(g[2 * H + j]), og = sigmoidf_(g[3 * H + j]);
+    const float tc = tanhf(c_out[i]);
+    const float dhv = dh[i];
+    const float dct = (dc ? dc[i] : 0.f) + dhv * og * (1.f - tc * tc);
+    float* d = dgates + (size_t)b * 4 * H;
+    d[j] = dct * gg * ig * (1.f - ig);
+    d[H + j] = dct * c_in[i] * fg * (1.f - fg);
+    d[2 * H + j] = dct * ig * (1.f - gg * gg);
+    d[3 * H + j] = dhv * tc * og * (1.f - og);
+    dc_prev[i] = dct * fg;
+}
+
+int lstm_bwd_f32(const float* gates, const float* c_in, const float* c_out, const float* dh, const float* dc, int B, int H,
+                 float* dgates, float* dc_prev, hipStream_t st) {
+    if (!gates || !c_in || !c_out || !dh || !dgates || !dc_prev || B <= 0 || H <= 0) { set_error("lstm_bwd: bad arguments"); return ICAP_ERR_ARG; }
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, gates, c_in, c_out, dh, dc, B, H, dgates, dc_prev);
+    return launch_status("lstm_bwd");
+}
+
+// ---------------------------------------------------------------- additive attention gradient
+// Forward (transformer_word_level_bahdnau.py:102-110): score[i][j] = a_w . tanh(u[j] + w[i]) + a_b,
+// alpha[i] = softmax_j(score[i]), context[i] = sum_j alpha[i][j] feat[j].
+// Query side, one workgroup per i:  dalpha[i][j] = dctx[i] . feat[j];
+//   dscore[i][j] = alpha[i][j] * (dalpha[i][j] - sum_j' alpha[i][j'] dalpha[i][j']);
+//   dw[i][a] = sum_j dscore[i][j] * a_w[a] * (1 - tanh(u[j][a] + w[i][a])^2);
+//   da_part[i][a] = sum_j dscore[i][j] * tanh(u[j][a] + w[i][a]);   dab_part[i] = sum_j dscore[i][j].
+constexpr int ATT_MAX_B = 1024;
+
+__global__ __launch_bounds__(256) void att_bwd_query_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                            const float* __restrict__ a_w, const float* __restrict__ alpha,
+                                                            const float* __restrict__ feat, const float* __restrict__ dctx,
+                                                            int B, int A, int E, float* __restrict__ dscore,
+                                                            float* __restrict__ dw, float* __restrict__ da_part,
+                                                            float* __restrict__ dab_part) {
+    __shared__ float ds[ATT_MAX_B];
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int j = wave; j < B; j += 4) {
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) s = fmaf(dctx[(size_t)i * E + e], feat[(size_t)j * E + e], s);
+        s = wave_sum(s);
+        if (lane == 0) ds[j] = s;   // dalpha
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int j = tid; j < B; j += 256) dot += alpha[(size_t)i * B + j] * ds[j];
+    dot = wave_sum(dot);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    dot = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    float tot = 0.f;
+    for (int j = tid; j < B; j += 256) {
+        const float v = alpha[(size_t)i * B + j] * (ds[j] - dot);
+        ds[j] = v;
+        dscore[(size_t)i * B + j] = v;
+        tot += v;
+    }
+    tot = wave_sum(tot);
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
+    if (tid == 0) dab_part[i] = ((red[0] + red[1]) + red[2]) + red[3];
+    for (int a = tid; a < A; a += 256) {
+        const float wi = w[(size_t)i * A + a], aw = a_w[a];
+        float accw = 0.f, acca = 0.f;
+        for (int j = 0; j < B; ++j) {
+            const float t = tanhf(u[(size_t)j * A + a] + wi);
+            accw += ds[j] * (1.f - t * t);
+            acca += ds[j] * t;
+        }
+        dw[(size_t)i * A + a] = accw * aw;
+        da_part[(size_t)i * A + a] = acca;
+    }
+}
+
+// Key side, one workgroup per j:  du[j][a] (+)= sum_i dscore[i][j] * a_w[a] * (1 - tanh(u[j][a] + w[i][a])^2);
+//   dfeat[j][e] (+)= sum_i alpha[i][j] * dctx[i][e].
+__global__ __launch_bounds__(256) void att_bwd_key_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                          const float* __restrict__ a_w, const float* __restrict__ alpha,
+                                                          const float* __restrict__ dscore, const float* __restrict__ dctx,
+                                                          int B, int A, int E, int accumulate, float* __restrict__ du,
+                                                          float* __restrict__ dfeat) {
+    const int j = blockIdx.x, tid = threadIdx.x;
+    for (int a = tid; a < A; a += 256) {
+        const float uj = u[(size_t)j * A + a];
+        float acc = 0.f;
+        for (int i = 0; i < B; ++i) {
+            const float t = tanhf(uj + w[(size_t)i * A + a]);
+            acc += dscore[(size_t)i * B + j] * (1.f - t * t);
+        }
+        const size_t o = (size_t)j * A + a;
+        du[o] = (accumulate ? du[o] : 0.f) + acc * a_w[a];
+    }
+    for (int e = tid; e < E; e += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < B; ++i) acc += alpha[(size_t)i * B + j] * dctx[(size_t)i * E + e];
+        const size_t o = (size_t)j * E + e;
+        dfeat[o] = (accumulate ? dfeat[o] : 0.f) + acc;
+    }
+}
+
+int att_bwd_f32(const float* u, const float* w, const float* a_w, const float* alpha, const float* feat, const float* dctx, int B,
+                int A, int E, int accumulate, float* dscore, float* dw, float* da_part, float* dab_part, float* du, float* dfeat,
+                hipStream_t st) {
+    if (!u || !w || !a_w || !alpha || !feat || !dctx || !dscore || !dw || !da_part || !dab_part || !du || !dfeat || B <= 0 ||
+        A <= 0 || E <= 0) {
+        set_error("att_bwd: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (B > ATT_MAX_B) { set_error("att_bwd: batch %d exceeds %d", B, ATT_MAX_B); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(att_bwd_query_kernel, dim3(B), dim3(256), 0, st, u, w, a_w, alpha, feat, dctx, B, A, E, dscore, dw, da_part, dab_part);
+    hipLaunchKernelGGL(att_bwd_key_kernel, dim3(B), dim3(256), 0, st, u, w, a_w, alpha, dscore, dctx, B, A, E, accumulate, du, dfeat);
+    return launch_status("att_bwd");
+}
+
+// ---------------------------------------------------------------- embedding gradient
+// dtable[idx[p]][:] += dy[p][:] for p in order.  Workgroup g owns the table rows with row % gridDim.x == g, so
+// every row is updated by one workgroup in position order: deterministic without atomics.  dtable must be
+// zeroed (or hold the value to accumulate onto) before the call.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dy, int ldd,
+                                                            int P, int E, int V, float* __restrict__ dtable) {
+    for (int p = 0; p < P; ++p) {
+        const long long t = idx[p];
+        if (t < 0 || t >= V || (int)(t % gridDim.x) != (int)blockIdx.x) continue;
+        for (int e = threadIdx.x; e < E; e += 256) dtable[(size_t)t * E + e] += dy[(size_t)p * ldd + e];
+    }
+}
+
+int embedding_bwd_f32(const long long* idx, const float* dy, int ldd, int P, int E, int V, float* dtable, hipStream_t st) {
+    if (!idx || !dy || !dtable || P <= 0 || E <= 0 || V <= 0 || ldd < E) { set_error("embedding_bwd: bad arguments"); return ICAP_ERR_ARG; }
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(256), dim3(256), 0, st, idx, dy, ldd, P, E, V, dtable);
+    return launch_status("embedding_bwd");
+}
+
+}  // namespace icap

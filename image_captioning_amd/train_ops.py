@@ -1,0 +1,211 @@
+"""Tensor-level wrappers over the training-step entry points of the C ABI (backward GEMMs, column
+reductions, BatchNorm / LayerNorm in training mode, dropout, cell / attention / embedding gradients).
+
+Same contract as ``ops``: fp32 contiguous tensors on the HIP device, no CPU path, every arithmetic
+operation runs in ``libicap_hip.so``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as N
+from .ops import ACT_NONE, _ck, _stream
+
+COL_SUM, COL_SQDEV, COL_BN_BWD, COL_LN_BWD = 0, 1, 2, 3
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _ckr(t, name):
+    """fp32 matrix on the device whose rows are contiguous (a row stride larger than the width is fine)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise N.IcapError(f"{name}: expected a tensor on the HIP device; the MI355X path has no CPU fallback")
+    if t.dtype != torch.float32 or t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1) or (t.size(0) > 1 and t.stride(0) < t.size(1)):
+        raise N.IcapError(f"{name}: expected an fp32 [rows, cols] matrix with contiguous rows")
+
+
+def _ws(n: int, dev) -> torch.Tensor | None:
+    return torch.empty(max(int(n), 1), device=dev, dtype=torch.float32) if n > 0 else None
+
+
+def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+    """out[M, N] (+)= a[M, K] @ b[K, N]  (input gradient of a Linear: dX = dY @ W)."""
+    _ckr(a, "a"); _ckr(b, "b")
+    M, K = a.shape
+    K2, Nn = b.shape
+    if K != K2:
+        raise N.IcapError(f"gemm_nn: inner sizes differ ({K} vs {K2})")
+    if out is None:
+        out = torch.empty(M, Nn, device=a.device, dtype=torch.float32)
+        accumulate = False
+    lib = N.load()
+    ws = _ws(lib.icap_gemm_bwd_ws_floats(M, Nn, K, int(accumulate)), a.device)
+    N.check(lib.icap_gemm_bwd_f32(a.data_ptr(), a.stride(0), 0, b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, Nn, K,
+                                  int(accumulate), _p(ws), _stream()), "gemm_nn")
+    return out
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+    """out[M, N] (+)= a[K, M].T @ b[K, N]  (weight gradient of a Linear: dW = dY.T @ X)."""
+    _ckr(a, "a"); _ckr(b, "b")
+    K, M = a.shape
+    K2, Nn = b.shape
+    if K != K2:
+        raise N.IcapError(f"gemm_tn: contraction sizes differ ({K} vs {K2})")
+    if out is None:
+        out = torch.empty(M, Nn, device=a.device, dtype=torch.float32)
+        accumulate = False
+    lib = N.load()
+    ws = _ws(lib.icap_gemm_bwd_ws_floats(M, Nn, K, int(accumulate)), a.device)
+    N.check(lib.icap_gemm_bwd_f32(a.data_ptr(), a.stride(0), 1, b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, Nn, K,
+                                  int(accumulate), _p(ws), _stream()), "gemm_tn")
+    return out
+
+
+def col_reduce(mode: int, a, x=None, v1=None, v2=None, v3=None, v4=None, r1=None, r2=None, act=ACT_NONE, scale=1.0,
+               out1=None, out2=None, accumulate=False):
+    """Column reductions over a [M, C] matrix (see icap_col_reduce_f32); returns (out1, out2)."""
+    _ckr(a, "a")
+    M, C = a.shape
+    dev = a.device
+    two = mode >= COL_BN_BWD
+    if out1 is None:
+        out1 = torch.empty(C, device=dev, dtype=torch.float32)
+        accumulate = False
+    if two and out2 is None:
+        out2 = torch.empty(C, device=dev, dtype=torch.float32)
+    lib = N.load()
+    ws = _ws(lib.icap_col_reduce_ws_floats(M, C), dev)
+    N.check(lib.icap_col_reduce_f32(mode, a.data_ptr(), a.stride(0), _p(x), x.stride(0) if x is not None else 0, _p(v1), _p(v2), _p(v3),
+                                    _p(v4), _p(r1), _p(r2), act, M, C, float(scale), int(accumulate), out1.data_ptr(), _p(out2),
+                                    ws.data_ptr(), _stream()), "col_reduce")
+    return out1, out2
+
+
+def col_sum(a, out=None, accumulate=False, scale=1.0):
+    return col_reduce(COL_SUM, a, out1=out, accumulate=accumulate, scale=scale)[0]
+
+
+def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NONE, res=None):
+    """BatchNorm over the rows of x [M, C] with batch statistics (+ activation, + residual); updates the running
+    statistics in place.  Returns (y, saved) with saved = (mean, rstd, s, b) for the backward pass."""
+    _ckr(x, "x")
+    M, C = x.shape
+    dev = x.device
+    mean = col_reduce(COL_SUM, x, scale=1.0 / M)[0]
+    sqdev = col_reduce(COL_SQDEV, x, v1=mean)[0]
+    rstd = torch.empty(C, device=dev); s = torch.empty(C, device=dev); b = torch.empty(C, device=dev)
+    lib = N.load()
+    N.check(lib.icap_bn_finalize_f32(mean.data_ptr(), sqdev.data_ptr(), _p(gamma), _p(beta), float(eps), float(momentum), M, C,
+                                     rstd.data_ptr(), s.data_ptr(), b.data_ptr(), _p(run_mean), _p(run_var), _stream()), "bn_finalize")
+    y = scale_bias_act(x, s, b, act=act, res=res)
+    return y, (mean, rstd, s, b)
+
+
+def scale_bias_act(x, s=None, b=None, act=ACT_NONE, res=None, out=None):
+    _ckr(x, "x")
+    M, C = x.shape
+    if out is None:
+        out = torch.empty(M, C, device=x.device, dtype=torch.float32)
+    N.check(N.load().icap_scale_bias_act_f32(x.data_ptr(), x.stride(0), _p(s), _p(b), _p(res), res.stride(0) if res is not None else 0,
+                                             act, M, C, out.data_ptr(), out.stride(0), _stream()), "scale_bias_act")
+    return out
+
+
+def batchnorm_act_bwd(dy, x, saved, act=ACT_NONE, affine=True):
+    """Gradient of y = act(BatchNorm_train(x)): returns (dx, dgamma, dbeta)."""
+    mean, rstd, s, b = saved
+    M, C = x.shape
+    dbeta, dgamma = col_reduce(COL_BN_BWD, dy, x=x, v1=mean, v2=rstd, v3=s, v4=b, act=act)
+    dx = torch.empty(M, C, device=x.device, dtype=torch.float32)
+    N.check(N.load().icap_bn_act_bwd_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), s.data_ptr(), b.data_ptr(),
+                                         mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), act, M, C,
+                                         dx.data_ptr(), dx.stride(0), _stream()), "bn_act_bwd")
+    return dx, dgamma, dbeta
+
+
+def act_bwd(dy, z, act, s=None, b=None):
+    """dy * act'(z*s + b) * s  (activation after an eval-style affine, or a bare activation with s = b = None)."""
+    M, C = z.shape
+    dx = torch.empty(M, C, device=z.device, dtype=torch.float32)
+    N.check(N.load().icap_bn_act_bwd_f32(dy.data_ptr(), dy.stride(0), z.data_ptr(), z.stride(0), _p(s), _p(b), None, None, None, None,
+                                         act, M, C, dx.data_ptr(), dx.stride(0), _stream()), "act_bwd")
+    return dx
+
+
+def axpby(x, y, alpha=1.0, beta=1.0):
+    """y = alpha*x + beta*y in place."""
+    N.check(N.load().icap_axpby_f32(x.data_ptr(), float(alpha), float(beta), y.data_ptr(), x.numel(), _stream()), "axpby")
+    return y
+
+
+def dropout(x, p, seed, offset, group=1):
+    """Returns (y, mask); mask has x.numel() // group entries (0 or 1/(1-p))."""
+    _ck(x, "x")
+    n = x.numel()
+    y = torch.empty_like(x)
+    mask = torch.empty(n // group, device=x.device, dtype=torch.float32)
+    N.check(N.load().icap_dropout_f32(x.data_ptr(), float(p), int(seed) & (2 ** 64 - 1), int(offset), n, group, y.data_ptr(),
+                                      mask.data_ptr(), _stream()), "dropout")
+    return y, mask
+
+
+def mul_mask(x, mask, group=1, add=None):
+    y = torch.empty_like(x)
+    N.check(N.load().icap_mul_mask_f32(x.data_ptr(), mask.data_ptr(), group, _p(add), x.numel(), y.data_ptr(), _stream()), "mul_mask")
+    return y
+
+
+def layernorm_train(x, gamma, beta, res=None, eps=1e-5, pre_scale=1.0):
+    """Returns (y, saved) with saved = (xs, mean, rstd)."""
+    _ck(x, "x")
+    R, E = x.shape
+    dev = x.device
+    y = torch.empty(R, E, device=dev); xs = torch.empty(R, E, device=dev)
+    mean = torch.empty(R, device=dev); rstd = torch.empty(R, device=dev)
+    N.check(N.load().icap_ln_train_fwd_f32(x.data_ptr(), _p(res), gamma.data_ptr(), beta.data_ptr(), float(eps), float(pre_scale), R, E,
+                                           y.data_ptr(), xs.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream()), "ln_train_fwd")
+    return y, (xs, mean, rstd)
+
+
+def layernorm_bwd(dy, saved, gamma, post_scale=1.0):
+    """Returns (dx, dgamma, dbeta); dx is the gradient with respect to x (and to the residual) times post_scale."""
+    xs, mean, rstd = saved
+    R, E = xs.shape
+    dx = torch.empty(R, E, device=xs.device)
+    N.check(N.load().icap_ln_bwd_f32(dy.data_ptr(), xs.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), float(post_scale),
+                                     R, E, dx.data_ptr(), _stream()), "ln_bwd")
+    dbeta, dgamma = col_reduce(COL_LN_BWD, dy, x=xs, r1=mean, r2=rstd)
+    return dx, dgamma, dbeta
+
+
+def lstm_bwd(gates, c_in, c_out, dh, dc):
+    B, H4 = gates.shape
+    H = H4 // 4
+    dg = torch.empty(B, H4, device=gates.device); dcp = torch.empty(B, H, device=gates.device)
+    N.check(N.load().icap_lstm_bwd_f32(gates.data_ptr(), c_in.data_ptr(), c_out.data_ptr(), dh.data_ptr(), _p(dc), B, H, dg.data_ptr(),
+                                       dcp.data_ptr(), _stream()), "lstm_bwd")
+    return dg, dcp
+
+
+def attention_bwd(u, w, a_w, alpha, feat, dctx, du, dfeat, accumulate):
+    """Returns (dw [B, A], da_part [B, A], dab_part [B]); du / dfeat are written or accumulated in place."""
+    B, A = u.shape
+    E = feat.shape[1]
+    dev = u.device
+    dscore = torch.empty(B, B, device=dev); dw = torch.empty(B, A, device=dev)
+    da_part = torch.empty(B, A, device=dev); dab_part = torch.empty(B, device=dev)
+    N.check(N.load().icap_att_bwd_f32(u.data_ptr(), w.data_ptr(), a_w.data_ptr(), alpha.data_ptr(), feat.data_ptr(), dctx.data_ptr(), B, A, E,
+                                      int(accumulate), dscore.data_ptr(), dw.data_ptr(), da_part.data_ptr(), dab_part.data_ptr(),
+                                      du.data_ptr(), dfeat.data_ptr(), _stream()), "att_bwd")
+    return dw, da_part, dab_part
+
+
+def embedding_bwd(idx, dy, V):
+    """dtable [V, E] = scatter-add of dy rows by idx (deterministic)."""
+    P, E = dy.shape
+    dt = torch.zeros(V, E, device=dy.device)
+    N.check(N.load().icap_embedding_bwd_f32(idx.data_ptr(), dy.data_ptr(), dy.stride(0), P, E, V, dt.data_ptr(), _stream()), "embedding_bwd")
+    return dt

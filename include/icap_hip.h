@@ -260,6 +260,77 @@ int icap_ce_loss_bwd_f32(const float* logits, int ld, int group_rows, int group_
 int icap_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------ training step: backward GEMMs
+ * C[M][N] (+)= op(A) . B, B stored [K][N]; op(A) = A stored [M][K] (a_kmajor = 0: dX = dY . W, the input
+ * gradient of every nn.Linear / 1x1 convolution) or A stored [K][M] (a_kmajor = 1: dW = dY^T . X, the weight
+ * gradient, contraction over batch x positions).  ws: icap_gemm_bwd_ws_floats(M, N, K, accumulate) floats
+ * (may be NULL when that is 0).  loss.backward() of transformer_word_level_bahdnau.py:232 through every
+ * Linear of :22,60-66,98-100,122 and every 1x1 convolution of the EfficientNet of :14. */
+int icap_gemm_bwd_f32(const float* a, int lda, int a_kmajor, const float* b, int ldb, float* c, int ldc, int M, int N,
+                      int K, int accumulate, float* ws, void* stream);
+long long icap_gemm_bwd_ws_floats(int M, int N, int K, int accumulate);
+
+/* Column reductions over a [M][C] matrix, two passes in a fixed order.  mode 0: out1 = sum a (bias gradients,
+ * BatchNorm mean with scale 1/M); 1: out1 = sum (a - v1[c])^2; 2: BatchNorm gradient sums out1 = sum g,
+ * out2 = sum g * xhat with g = a * act'(x*v3 + v4), xhat = (x - v1) * v2; 3: LayerNorm parameter gradients
+ * out1 = sum a, out2 = sum a * (x - r1[r]) * r2[r].  Results are multiplied by scale and optionally added onto
+ * out.  ws: icap_col_reduce_ws_floats(M, C) floats.  nn.BatchNorm1d / BatchNorm2d in train mode
+ * (transformer_word_level_bahdnau.py:64,123 and the EfficientNet blocks) and nn.LayerNorm (:57-58). */
+int icap_col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, const float* v1, const float* v2,
+                        const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C,
+                        float scale, int accumulate, float* out1, float* out2, float* ws, void* stream);
+long long icap_col_reduce_ws_floats(int M, int C);
+
+/* BatchNorm in training mode: from the batch mean and the summed squared deviations compute rstd, the fused
+ * normalisation y = x*s + b, and update the running statistics with `momentum` (unbiased variance). */
+int icap_bn_finalize_f32(const float* mean, const float* sqdev, const float* gamma, const float* beta, float eps,
+                         float momentum, int M, int C, float* rstd, float* s, float* b, float* run_mean,
+                         float* run_var, void* stream);
+
+/* y = act(x * s[c] + b[c]) (+ res): normalisation + activation (+ identity skip) over [M][C]. */
+int icap_scale_bias_act_f32(const float* x, int ldx, const float* s, const float* b, const float* res, int ldr, int act,
+                            int M, int C, float* y, int ldy, void* stream);
+
+/* Gradient of y = act(BatchNorm(x)) with respect to x (mean == NULL: plain per-channel affine + activation). */
+int icap_bn_act_bwd_f32(const float* dy, int ldd, const float* x, int ldx, const float* s, const float* b,
+                        const float* mean, const float* rstd, const float* dgamma, const float* dbeta, int act, int M,
+                        int C, float* dx, int ldo, void* stream);
+
+/* y = alpha*x + beta*y (gradient accumulation where a tensor feeds several consumers). */
+int icap_axpby_f32(const float* x, float alpha, float beta, float* y, long long n, void* stream);
+
+/* nn.Dropout(p) in train mode (transformer_word_level_bahdnau.py:63,66,68,125) and, with group = elements per
+ * sample, the EfficientNet drop-connect: y = x * mask, mask = 0 or 1/(1-p) from a counter-based generator keyed
+ * by (seed, offset + index / group); mask [n / group] is kept for the backward pass. */
+int icap_dropout_f32(const float* x, float p, unsigned long long seed, unsigned long long offset, long long n,
+                     long long group, float* y, float* mask, void* stream);
+/* y = x * mask[i / group] (+ add): re-applies a stored mask (backward of dropout; forward with a given mask). */
+int icap_mul_mask_f32(const float* x, const float* mask, long long group, const float* add, long long n, float* y,
+                      void* stream);
+
+/* nn.LayerNorm in a training step: forward keeps the normalised-input xs = (x (+ res)) * pre_scale, mean and
+ * rstd per row; backward returns d/dx (times post_scale).  transformer_word_level_bahdnau.py:77,88. */
+int icap_ln_train_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                          float pre_scale, int R, int E, float* y, float* xs, float* mean, float* rstd, void* stream);
+int icap_ln_bwd_f32(const float* dy, const float* xs, const float* gamma, const float* mean, const float* rstd,
+                    float post_scale, int R, int E, float* dx, void* stream);
+
+/* Gradient of one nn.LSTMCell step (transformer_word_level_bahdnau.py:136) with respect to the gate
+ * pre-activations [B][4H] and the previous cell state, from dh and the dc arriving from step t+1. */
+int icap_lstm_bwd_f32(const float* gates, const float* c_in, const float* c_out, const float* dh, const float* dc,
+                      int B, int H, float* dgates, float* dc_prev, void* stream);
+
+/* Gradient of Attention.forward (transformer_word_level_bahdnau.py:102-110) for one decode step: from dctx
+ * [B][E] to dw [B][A] (query projections), du [B][A] and dfeat [B][E] (key side, optionally accumulated over
+ * steps), per-query partials da_part [B][A], dab_part [B] of the scoring vector's gradient, dscore [B][B]. */
+int icap_att_bwd_f32(const float* u, const float* w, const float* a_w, const float* alpha, const float* feat,
+                     const float* dctx, int B, int A, int E, int accumulate, float* dscore, float* dw, float* da_part,
+                     float* dab_part, float* du, float* dfeat, void* stream);
+
+/* nn.Embedding gradient: dtable[idx[p]] += dy[p], positions in order (deterministic); dtable pre-zeroed. */
+int icap_embedding_bwd_f32(const long long* idx, const float* dy, int ldd, int P, int E, int V, float* dtable,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

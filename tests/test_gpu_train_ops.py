@@ -1,0 +1,167 @@
+"""GPU parity of the backward / training-mode kernels against torch's CPU autograd on the same inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torch_ref as O
+
+pytestmark = pytest.mark.gpu
+D = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("M,K,N", [(240, 6756, 512), (12, 512, 1024), (64, 256, 2048), (7, 20, 36), (588, 1152, 192), (130, 100, 70)])
+def test_gemm_nn(M, K, N):
+    from image_captioning_amd import train_ops as T
+    a, b = rnd(M, K, seed=1), rnd(K, N, seed=2) * K ** -0.5
+    got = T.gemm_nn(a.to(D), b.to(D)).cpu()
+    torch.testing.assert_close(got, a.double().mm(b.double()).float(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("K,M,N", [(240, 6756, 512), (150528, 96, 16), (12, 512, 1024), (3136, 144, 24), (37, 20, 36), (2352, 1152, 192)])
+def test_gemm_tn(K, M, N):
+    from image_captioning_amd import train_ops as T
+    a, b = rnd(K, M, seed=3), rnd(K, N, seed=4) * K ** -0.5
+    want = a.double().t().mm(b.double()).float()
+    got = T.gemm_tn(a.to(D), b.to(D)).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-4)
+    base = rnd(M, N, seed=5)
+    acc = base.to(D)
+    T.gemm_tn(a.to(D), b.to(D), out=acc, accumulate=True)
+    torch.testing.assert_close(acc.cpu(), base + want, rtol=1e-4, atol=2e-4)
+
+
+def test_gemm_strided_rows():
+    """Operands that are column slices of wider matrices (gate blocks of an LSTM weight, halves of a concatenation)."""
+    from image_captioning_amd import train_ops as T
+    big_a, big_b = rnd(40, 300, seed=6), rnd(128, 200, seed=7)
+    a, b = big_a[:, 100:228], big_b[:, 40:140]
+    got = T.gemm_nn(big_a.to(D)[:, 100:228], big_b.to(D)[:, 40:140]).cpu()
+    torch.testing.assert_close(got, a.mm(b), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,C", [(12, 6756), (3000, 96), (64, 512), (5, 7)])
+def test_col_sum(M, C):
+    from image_captioning_amd import train_ops as T
+    a = rnd(M, C, seed=8)
+    torch.testing.assert_close(T.col_sum(a.to(D)).cpu(), a.double().sum(0).float(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,C,act", [(12, 6756, 0), (1568, 96, 2), (12, 512, 0), (49, 1152, 2)])
+def test_batchnorm_train_forward_backward(M, C, act):
+    from image_captioning_amd import train_ops as T
+    x = (rnd(M, C, seed=9) * 2 + 0.5).requires_grad_(True)
+    gamma = (rnd(C, seed=10) * 0.2 + 1).requires_grad_(True)
+    beta = (rnd(C, seed=11) * 0.3).requires_grad_(True)
+    rm, rv = rnd(C, seed=12), rnd(C, seed=13).abs() + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.01, eps=1e-3)
+    if act == 2:
+        y = y * torch.sigmoid(y)
+    dy = rnd(M, C, seed=14)
+    y.backward(dy)
+    rm_g, rv_g = rm.to(D), rv.to(D)
+    yg, saved = T.batchnorm_train(x.detach().to(D), gamma.detach().to(D), beta.detach().to(D), rm_g, rv_g, 1e-3, 0.01, act=act)
+    dx, dgam, dbet = T.batchnorm_act_bwd(dy.to(D), x.detach().to(D), saved, act=act)
+    torch.testing.assert_close(yg.cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rm_g.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv_g.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dgam.cpu(), gamma.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(dbet.cpu(), beta.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("R,E,res,pre", [(12, 512, False, 1.0), (12, 512, True, 1.0), (5, 512, False, 2.0), (3, 96, True, 1.0)])
+def test_layernorm_train_forward_backward(R, E, res, pre):
+    from image_captioning_amd import train_ops as T
+    x = rnd(R, E, seed=15).requires_grad_(True)
+    r = rnd(R, E, seed=16).requires_grad_(True) if res else None
+    g = (rnd(E, seed=17) * 0.1 + 1).requires_grad_(True)
+    b = (rnd(E, seed=18) * 0.1).requires_grad_(True)
+    inp = (x + r if res else x) * pre
+    y = F.layer_norm(inp, (E,), g, b, 1e-5)
+    dy = rnd(R, E, seed=19)
+    y.backward(dy)
+    yg, saved = T.layernorm_train(x.detach().to(D), g.detach().to(D), b.detach().to(D), res=r.detach().to(D) if res else None, pre_scale=pre)
+    dx, dg, db = T.layernorm_bwd(dy.to(D), saved, g.detach().to(D), post_scale=pre)
+    torch.testing.assert_close(yg.cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(dg.cpu(), g.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-5)
+
+
+def test_dropout_mask_and_rate():
+    from image_captioning_amd import train_ops as T
+    x = torch.ones(200, 512, device=D)
+    y, mask = T.dropout(x, 0.3, seed=1234, offset=0)
+    kept = (mask > 0).float().mean().item()
+    assert abs(kept - 0.7) < 0.01
+    assert torch.equal(y, mask.view_as(y))
+    vals = mask.unique().cpu()
+    torch.testing.assert_close(vals, torch.tensor([0.0, 1 / 0.7]))
+    y2, mask2 = T.dropout(x, 0.3, seed=1234, offset=0)
+    assert torch.equal(mask, mask2)                                  # same (seed, offset) -> same mask
+    _, mask3 = T.dropout(x, 0.3, seed=1234, offset=x.numel())
+    assert not torch.equal(mask, mask3)
+    # per-sample decisions (drop-connect): one factor per group of elements
+    z, m = T.dropout(torch.ones(64, 100, device=D), 0.2, seed=7, offset=0, group=100)
+    assert m.numel() == 64 and torch.equal(z, m[:, None].expand(64, 100))
+    g = T.mul_mask(torch.full((64, 100), 2.0, device=D), m, group=100)
+    assert torch.equal(g, 2 * z)
+
+
+def test_lstm_cell_gradient():
+    from image_captioning_amd import train_ops as T
+    B, H = 12, 512
+    gates = rnd(B, 4 * H, seed=20).requires_grad_(True)
+    c_in = rnd(B, H, seed=21).requires_grad_(True)
+    i, f, g, o = gates.chunk(4, 1)
+    c = torch.sigmoid(f) * c_in + torch.sigmoid(i) * torch.tanh(g)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    dh, dc = rnd(B, H, seed=22), rnd(B, H, seed=23)
+    torch.autograd.backward([h, c], [dh, dc])
+    dg, dcp = T.lstm_bwd(gates.detach().to(D), c_in.detach().to(D), c.detach().to(D), dh.to(D), dc.to(D))
+    torch.testing.assert_close(dg.cpu(), gates.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(dcp.cpu(), c_in.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B", [1, 12, 37])
+def test_additive_attention_gradient(B):
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd import ops
+    A, E = 256, 512
+    u = rnd(B, A, seed=24).requires_grad_(True)
+    w = rnd(B, A, seed=25).requires_grad_(True)
+    a_w = (rnd(A, seed=26) * 0.2).requires_grad_(True)
+    a_b = torch.tensor(0.1, requires_grad=True)
+    feat = rnd(B, E, seed=27).requires_grad_(True)
+    score = (torch.tanh(u[None, :, :] + w[:, None, :]) * a_w).sum(-1) + a_b       # [i, j]
+    alpha = torch.softmax(score, dim=1)
+    ctx = alpha @ feat
+    dctx = rnd(B, E, seed=28)
+    ctx.backward(dctx)
+    alpha_g, _ = ops.bahdanau_attention(u.detach().to(D), w.detach().to(D), a_w.detach().to(D), 0.1, feat.detach().to(D))
+    du = torch.zeros(B, A, device=D); dfeat = torch.zeros(B, E, device=D)
+    dw, da_part, dab_part = T.attention_bwd(u.detach().to(D), w.detach().to(D), a_w.detach().to(D), alpha_g, feat.detach().to(D),
+                                            dctx.to(D), du, dfeat, accumulate=False)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(du.cpu(), u.grad, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(dfeat.cpu(), feat.grad, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(da_part.sum(0).cpu(), a_w.grad, rtol=1e-3, atol=1e-5)
+    # softmax is shift invariant: the exact gradient of the scoring bias is 0, both sides hold rounding noise
+    torch.testing.assert_close(dab_part.sum().cpu(), a_b.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_embedding_gradient_is_deterministic_scatter_add():
+    from image_captioning_amd import train_ops as T
+    V, E, P = 97, 64, 300
+    idx = torch.randint(0, V, (P,), generator=torch.Generator().manual_seed(1))
+    dy = rnd(P, E, seed=29)
+    want = torch.zeros(V, E).index_add_(0, idx, dy)
+    got = T.embedding_bwd(idx.to(D), dy.to(D), V)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+    assert torch.equal(got, T.embedding_bwd(idx.to(D), dy.to(D), V))

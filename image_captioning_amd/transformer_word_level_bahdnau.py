@@ -2,7 +2,8 @@
 
 Drop-in for the model classes of the reference's transformer_word_level_bahdnau.py:53-166:
 same names, constructor arguments, ``forward`` signatures and ``state_dict`` keys;
-eval-mode arithmetic in ``libicap_hip.so``.  (The reference's
+arithmetic in ``libicap_hip.so``: the inference kernels under ``model.eval()``, the training-mode
+forward with a hand-written backward (``_bah_train``) under ``model.train()``.  (The reference's
 ``TransformerEncoderBlock_antiguo``, lines 29-50, cannot be instantiated and has
 no counterpart here.)
 
@@ -53,9 +54,14 @@ class TransformerEncoderBlock(nn.Module):
                 "fc0": (_f32(self.fc[0].weight), _f32(self.fc[0].bias)),
                 "fc4": ((w4 * s[None, :]).contiguous(), (w4 @ b + b4).contiguous())}
 
+    dropout_masks = None   # tests: {"enc_att", "enc_fc1", "enc_fc2"} -> factor tensors, instead of generated masks
+
     def rows_forward(self, rows):
-        """rows [B, E] -> [B, E]; images are independent of each other in eval mode."""
-        require_eval(self, "TransformerEncoderBlock")
+        """rows [B, E] -> [B, E]; images are independent of each other in eval mode, coupled by BatchNorm1d's
+        batch statistics in train mode."""
+        if self.training:
+            from ._bah_train import encoder_block_train
+            return encoder_block_train(self, rows, self.dropout_masks)
         p = self._prep.get(self, self._build)
         a = p["att"]
         rows = rows.float().contiguous()
@@ -125,14 +131,18 @@ class BahdanauDecoder(nn.Module):
         dev = next(self.parameters()).device
         return (torch.zeros(batch_size, encoder_dim, device=dev), torch.zeros(batch_size, encoder_dim, device=dev))
 
+    dropout_masks = None   # tests: {"dec_out": [B, T, H] factors}, instead of generated masks
+
     def forward(self, captions, encoder_out):
         """captions [B, T], encoder_out [1, B, E] -> logits [B, T, V]; attention couples the batch."""
-        require_eval(self, "BahdanauDecoder")
-        p = self._weights()
         B, T = captions.shape
-        feats = encoder_out.reshape(-1, encoder_out.shape[-1]).float().contiguous()
-        if feats.shape[0] != B:
+        if encoder_out.numel() != B * encoder_out.shape[-1]:
             raise ValueError("BahdanauDecoder: encoder_out must hold one row per caption")
+        if self.training:
+            from ._bah_train import decoder_train
+            return decoder_train(self, captions, encoder_out.reshape(B, encoder_out.shape[-1]), self.dropout_masks)
+        p = self._weights()
+        feats = encoder_out.reshape(-1, encoder_out.shape[-1]).float().contiguous()
         h, c = self.init_hidden_state(B, encoder_out.size(-1))
         H = self.decoder_dim
         emb, _ = ops.embedding(p["emb"], captions.t().contiguous().view(-1))               # time-major rows
@@ -162,7 +172,6 @@ class ImageCaptioningModel(nn.Module):
         self.decoder = decoder
 
     def forward(self, images, captions):
-        require_eval(self, "ImageCaptioningModel")
         return self.forward_features(self.cnn_model(images), captions)
 
     def forward_features(self, img_features, captions):

@@ -110,3 +110,40 @@ def test_losses():
     pred, tgt = torch.from_numpy(g["pred"]), torch.from_numpy(g["tgt"])
     assert abs(float(R.compute_loss(pred, tgt, 0)) - float(g["compute_loss_pad0"])) < 1e-6
     assert abs(float(R.seq2seq_loss(pred, tgt, 0)) - float(g["ce_ignore0"])) < 1e-6
+
+
+def test_bahdanau_training_step_oracle_matches_reference():
+    """Train-mode forward + loss + every gradient of oracle.train_ref against the reference's classes
+    (dropout 0, tests/golden/bahdanau_train_small.npz from oracle/make_golden_train.py)."""
+    import numpy as np
+    from oracle import train_ref as TR
+    from image_captioning_amd import transformer_word_level_bahdnau as my_bah
+    from image_captioning_amd.synthetic import seeded_state_dict
+    g = H.load("bahdanau_train_small")
+    E, ENC, HD, A, V, DENSE, B, T, PAD = [int(v) for v in g["dims"]]
+    mine = my_bah.ImageCaptioningModel(torch.nn.Identity(), my_bah.TransformerEncoderBlock(ENC, DENSE, 8, dropout=0.0),
+                                       my_bah.BahdanauDecoder(E, ENC, HD, A, V, dropout=0.0))
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in seeded_state_dict(mine, seed=31).items()}
+    feats = torch.randn(B, ENC, generator=torch.Generator().manual_seed(501)).requires_grad_(True)
+    caps = torch.from_numpy(g["caps"])
+    enc_bn = {"running_mean": sd["encoder.fc.3.running_mean"].detach().clone(), "running_var": sd["encoder.fc.3.running_var"].detach().clone()}
+    dec_bn = {"running_mean": sd["decoder.fc.1.running_mean"].detach().clone(), "running_var": sd["decoder.fc.1.running_var"].detach().clone()}
+    pred = TR.bah_train_forward(sd, feats, caps, enc_bn, dec_bn)
+    loss = R.compute_loss(pred[:, :-1], caps[:, 1:], PAD)
+    loss.backward()
+    torch.testing.assert_close(pred.detach(), torch.from_numpy(g["logits"]), rtol=1e-4, atol=1e-5)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    torch.testing.assert_close(feats.grad, torch.from_numpy(g["grad_feats"]), rtol=1e-3, atol=1e-7)
+    for k in g:
+        if not k.startswith("grad.") or k == "grad.":
+            continue
+        name = k[5:]
+        want = torch.from_numpy(g[k])
+        if want.numel() == 0:
+            continue
+        got = sd[name].grad
+        if name.endswith("attention.in_proj_weight") or name.endswith("attention.in_proj_bias"):
+            got = torch.zeros_like(sd[name]) if got is None else got      # the oracle never touches the q / k rows
+        torch.testing.assert_close(got, want.view_as(got), rtol=2e-3, atol=2e-6, msg=lambda m: f"{name}: {m}")   # a bias in front of a train-mode BatchNorm has gradient 0 up to rounding
+    torch.testing.assert_close(dec_bn["running_mean"], torch.from_numpy(g["after.decoder.fc.1.running_mean"]), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(enc_bn["running_var"], torch.from_numpy(g["after.encoder.fc.3.running_var"]), rtol=1e-4, atol=1e-6)

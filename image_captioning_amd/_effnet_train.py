@@ -1,0 +1,203 @@
+"""Training-mode forward and hand-written backward of get_cnn_model: EfficientNet-B0 + Linear(1280, 512)
+(transformer_word_level_bahdnau.py:12-25 under ``model.train()``; the reference optimises every CNN parameter).
+
+efficientnet_pytorch train-mode semantics: BatchNorm with batch statistics (eps 1e-3, momentum 0.01), swish,
+squeeze-excite, drop-connect on the identity-skip blocks with rate 0.2 * block_index / 16 (one Bernoulli factor
+per sample), dropout 0.2 on the pooled feature.
+
+The whole CNN is ONE ``torch.autograd.Function``.  The forward records a tape of closures, one per layer, each
+holding what its gradient needs; the backward runs the tape in reverse.  Activations are NHWC fp32 viewed as
+[B*H*W, C] matrices, so a 1x1 convolution is a GEMM (forward: the MFMA implicit-GEMM kernel; input gradient:
+``gemm_nn``; weight gradient: ``gemm_tn`` with the contraction split across workgroups).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from . import train_ops as T
+from ._bah_train import DropoutState
+from .backbones import conv_weight_khwc, same_pad
+from .ops import ACT_NONE, ACT_SIGMOID, ACT_SWISH
+
+DROP_CONNECT_RATE = 0.2   # efficientnet-b0 global parameter
+HEAD_DROPOUT = 0.2
+
+
+class _Tape:
+    def __init__(self):
+        self.steps = []
+        self.grads = {}
+
+    def add(self, fn):
+        self.steps.append(fn)
+
+    def grad(self, param, value):
+        self.grads[id(param)] = value.view(param.shape) if value.shape != param.shape else value
+
+
+def _w2d(conv):
+    w = conv.weight.detach()
+    return w.reshape(w.shape[0], w.shape[1]).float().contiguous()
+
+
+def _bn_act(tape, z, bn, act):
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    y, saved = T.batchnorm_train(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, mom, act=act)
+    bn.num_batches_tracked += 1
+
+    def bwd(dy):
+        dx, dg, db = T.batchnorm_act_bwd(dy, z, saved, act=act)
+        tape.grad(bn.weight, dg)
+        tape.grad(bn.bias, db)
+        return dx
+    return y, bwd
+
+
+def _conv1x1(tape, x, conv, need_dx=True):
+    w = _w2d(conv)
+    z = ops.linear(x, w)
+
+    def bwd(dz):
+        tape.grad(conv.weight, T.gemm_tn(dz, x))
+        return T.gemm_nn(dz, w) if need_dx else None
+    return z, bwd
+
+
+def _mbconv(tape, blk, x, B, H, W, idx, masks):
+    """One MBConv block on x [B*H*W, cin]; returns (y, Ho, Wo) and pushes its backward closure."""
+    cin, cout, k, stride = blk.cin, blk.cout, blk.k, blk.stride
+    mid = cin * blk.expand
+    inp = x
+    bw = []                                  # layer closures of this block, forward order
+    a0 = x
+    if blk.expand != 1:
+        z0, f = _conv1x1(tape, x, blk._expand_conv); bw.append(f)
+        a0, f = _bn_act(tape, z0, blk._bn0, ACT_SWISH); bw.append(f)
+    lo, hi = same_pad(k, stride)
+    dw_w = blk._depthwise_conv.weight.detach().view(mid, k * k).t().float().contiguous()   # [k*k, C]
+    z1, _ = ops.dwconv2d(a0.view(B, H, W, mid), dw_w, ks=k, stride=stride, pad=(lo, hi, lo, hi))
+    Ho, Wo = z1.shape[1], z1.shape[2]
+    HW = Ho * Wo
+    z1 = z1.view(B * HW, mid)
+    a1, bn1_bwd = _bn_act(tape, z1, blk._bn1, ACT_SWISH)
+    # squeeze-excite
+    sq = blk._se_reduce.weight.shape[0]
+    wr, br = _w2d(blk._se_reduce), blk._se_reduce.bias.detach().float().contiguous()
+    we, be = _w2d(blk._se_expand), blk._se_expand.bias.detach().float().contiguous()
+    pooled = T.image_dot(a1, None, B, HW, mid, scale=1.0 / HW)
+    # the squeeze width (cin / 4) is not a multiple of 4 everywhere: these two tiny layers use the general GEMM
+    r_pre = T.scale_bias_act(T.gemm_nn(pooled, wr.t().contiguous()), None, br)
+    r = T.scale_bias_act(r_pre, act=ACT_SWISH)
+    e = T.scale_bias_act(T.gemm_nn(r, we.t().contiguous()), None, be)
+    gate = T.scale_bias_act(e, act=ACT_SIGMOID)
+    a2 = T.chan_affine(a1, gate, None, 0.0, B, HW, mid)
+    z2, proj_bwd = _conv1x1(tape, a2, blk._project_conv)
+    y, bn2_bwd = _bn_act(tape, z2, blk._bn2, ACT_NONE)
+    skip = stride == 1 and cin == cout
+    dc_mask = None
+    if skip:
+        rate = DROP_CONNECT_RATE * idx / 16.0
+        given = (masks or {}).get(f"dc{idx}") if masks is not None else None
+        if rate > 0 and given is not None:
+            dc_mask = given.reshape(-1).float().contiguous()
+            y = T.mul_mask(y, dc_mask, group=HW * cout, add=inp)
+        elif rate > 0 and masks is None:
+            y, dc_mask = T.dropout(y, rate, DropoutState.seed, DropoutState.take(B), group=HW * cout)
+            T.axpby(inp, y)
+        else:
+            y = T.scale_bias_act(y, res=inp)
+
+    def bwd(dy):
+        dyb = T.mul_mask(dy, dc_mask, group=HW * cout) if dc_mask is not None else dy
+        dz2 = bn2_bwd(dyb)
+        da2 = proj_bwd(dz2)
+        dgate = T.image_dot(da2, a1, B, HW, mid)
+        de = T.act_bwd(dgate, e, ACT_SIGMOID)
+        tape.grad(blk._se_expand.weight, T.gemm_tn(de, r))
+        tape.grad(blk._se_expand.bias, T.col_sum(de))
+        dr = T.gemm_nn(de, we)
+        dr_pre = T.act_bwd(dr, r_pre, ACT_SWISH)
+        tape.grad(blk._se_reduce.weight, T.gemm_tn(dr_pre, pooled))
+        tape.grad(blk._se_reduce.bias, T.col_sum(dr_pre))
+        dpooled = T.gemm_nn(dr_pre, wr)
+        da1 = T.chan_affine(da2, gate, dpooled, 1.0 / HW, B, HW, mid)
+        dz1 = bn1_bwd(da1)
+        dww = T.dwconv_bwd_weight(dz1, a0, B, H, W, mid, k, stride, lo, lo, Ho, Wo)
+        tape.grad(blk._depthwise_conv.weight, dww.t().contiguous().view(mid, 1, k, k))
+        d = T.dwconv_bwd_data(dz1, dw_w, B, H, W, mid, k, stride, lo, lo, Ho, Wo)
+        for f in reversed(bw):
+            d = f(d)
+        if skip:
+            T.axpby(dy, d)
+        return d
+    tape.add(bwd)
+    return y, Ho, Wo
+
+
+class CnnTrain(torch.autograd.Function):
+    """images [B, 3, H, W] -> [B, 512] in train mode; parameters are passed so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, images, model, masks, *params):
+        eff, lin = model[0], model[1]
+        tape = _Tape()
+        B, _, H, W = images.shape
+        x4 = ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)                       # [B, H, W, 4]
+        lo, hi = same_pad(3, 2)
+        w_stem = conv_weight_khwc(eff._conv_stem.weight.detach(), 4)
+        z = ops.conv2d(x4, w_stem, stride=2, pad=(lo, hi, lo, hi))
+        Ho, Wo = z.shape[1], z.shape[2]
+        z = z.view(B * Ho * Wo, 32)
+        a, bn0_bwd = _bn_act(tape, z, eff._bn0, ACT_SWISH)
+
+        def stem_bwd(da):
+            dz = bn0_bwd(da)
+            col = T.im2col(x4, B, H, W, 4, 3, 3, 2, lo, lo, Ho, Wo)                    # [M, 36]
+            dw = T.gemm_tn(dz, col).view(32, 3, 3, 4)[:, :, :, :3].permute(0, 3, 1, 2).contiguous()
+            tape.grad(eff._conv_stem.weight, dw)
+            return None
+        tape.add(stem_bwd)
+        x, H2, W2 = a, Ho, Wo
+        for idx, blk in enumerate(eff._blocks):
+            x, H2, W2 = _mbconv(tape, blk, x, B, H2, W2, idx, masks)
+        HW = H2 * W2
+        zh, head_bwd = _conv1x1(tape, x, eff._conv_head)
+        ah, bn1_bwd = _bn_act(tape, zh, eff._bn1, ACT_SWISH)
+        pooled = T.image_dot(ah, None, B, HW, 1280, scale=1.0 / HW)
+        given = (masks or {}).get("cnn_drop") if masks is not None else None
+        if given is not None:
+            m_drop = given.reshape(-1).float().contiguous()
+            pd = T.mul_mask(pooled, m_drop)
+        elif masks is None and HEAD_DROPOUT > 0:
+            pd, m_drop = T.dropout(pooled, HEAD_DROPOUT, DropoutState.seed, DropoutState.take(pooled.numel()))
+        else:
+            pd, m_drop = pooled, None
+        lw, lb = lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous()
+        out = ops.linear(pd, lw, lb)
+
+        def head(dout):
+            tape.grad(lin.weight, T.gemm_tn(dout, pd))
+            tape.grad(lin.bias, T.col_sum(dout))
+            dpd = T.gemm_nn(dout, lw)
+            dpool = T.mul_mask(dpd, m_drop) if m_drop is not None else dpd
+            da = T.chan_affine(None, None, dpool, 1.0 / HW, B, HW, 1280)
+            return head_bwd(bn1_bwd(da))
+        tape.add(head)
+        ctx.tape = tape
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tape = ctx.tape
+        d = dout.float().contiguous()
+        for f in reversed(tape.steps):
+            d = f(d)
+        return (None, None, None) + tuple(tape.grads.get(id(p)) for p in ctx.params)
+
+
+def cnn_train(model, images, masks=None):
+    """masks: None -> generated drop-connect / dropout; a dict -> exactly the given factors (missing key: no dropping)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    return CnnTrain.apply(images, model, masks, *params)

@@ -347,7 +347,12 @@ EfficientNet = EfficientNetB0
 class CnnModel(nn.Sequential):
     """``nn.Sequential(base_model, nn.Linear(1280, 512))`` of get_cnn_model (transformer_word_level.py:19-22)."""
 
+    dropout_masks = None   # tests: {"dc<i>": [B], "cnn_drop": [B, 1280]} factor tensors instead of generated masks
+
     def forward(self, images: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            from ._effnet_train import cnn_train
+            return cnn_train(self, images, self.dropout_masks)
         feat = self[0](images)
         lin = self[1]
         return ops.linear(feat, lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous())

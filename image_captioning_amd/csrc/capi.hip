@@ -76,6 +76,13 @@ int att_bwd_f32(const float*, const float*, const float*, const float*, const fl
                 float*, float*, float*, float*, float*, hipStream_t);
 int embedding_bwd_f32(const long long*, const float*, int, int, int, int, float*, hipStream_t);
 
+int chan_affine_f32(const float*, const float*, const float*, float, int, int, int, float*, hipStream_t);
+int image_dot_f32(const float*, const float*, int, int, int, float, float*, hipStream_t);
+int dwconv_bwd_data_f32(const float*, const float*, int, int, int, int, int, int, int, int, int, int, float*, hipStream_t);
+int dwconv_bwd_weight_f32(const float*, const float*, int, int, int, int, int, int, int, int, int, int, float*, float*, hipStream_t);
+long long dwconv_bwd_weight_ws_floats(int, int, int, int, int);
+int im2col_f32(const float*, int, int, int, int, int, int, int, int, int, int, int, float*, hipStream_t);
+
 static inline long long align4(long long n) { return (n + 3) & ~3LL; }
 
 #define ICAP_TRY(expr)            \
@@ -454,6 +461,30 @@ int icap_att_bwd_f32(const float* u, const float* w, const float* a_w, const flo
 
 int icap_embedding_bwd_f32(const long long* idx, const float* dy, int ldd, int P, int E, int V, float* dtable, void* stream) {
     return embedding_bwd_f32(idx, dy, ldd, P, E, V, dtable, (hipStream_t)stream);
+}
+
+int icap_chan_affine_f32(const float* x, const float* g, const float* a, float alpha, int B, int HW, int C, float* y, void* stream) {
+    return chan_affine_f32(x, g, a, alpha, B, HW, C, y, (hipStream_t)stream);
+}
+
+int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, void* stream) {
+    return image_dot_f32(x, y, B, HW, C, scale, out, (hipStream_t)stream);
+}
+
+int icap_dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, int C, int K, int S, int pad_t, int pad_l, int Ho,
+                             int Wo, float* dx, void* stream) {
+    return dwconv_bwd_data_f32(dy, w, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, dx, (hipStream_t)stream);
+}
+
+int icap_dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, int W, int C, int K, int S, int pad_t, int pad_l, int Ho,
+                               int Wo, float* dw, float* ws, void* stream) {
+    return dwconv_bwd_weight_f32(dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, dw, ws, (hipStream_t)stream);
+}
+long long icap_dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K) { return dwconv_bwd_weight_ws_floats(B, Ho, Wo, C, K); }
+
+int icap_im2col_f32(const float* x, int B, int H, int W, int C, int KH, int KW, int S, int pad_t, int pad_l, int Ho, int Wo, float* col,
+                    void* stream) {
+    return im2col_f32(x, B, H, W, C, KH, KW, S, pad_t, pad_l, Ho, Wo, col, (hipStream_t)stream);
 }
 
 }  // extern "C"

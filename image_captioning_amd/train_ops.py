@@ -209,3 +209,40 @@ def embedding_bwd(idx, dy, V):
     dt = torch.zeros(V, E, device=dy.device)
     N.check(N.load().icap_embedding_bwd_f32(idx.data_ptr(), dy.data_ptr(), dy.stride(0), P, E, V, dt.data_ptr(), _stream()), "embedding_bwd")
     return dt
+
+
+# ---------------------------------------------------------------------------- convolutional encoder
+def chan_affine(x, g, a, alpha, B, HW, C):
+    """y[b,p,c] = x*g[b][c] + a[b][c]*alpha over an NHWC tensor viewed as [B*HW, C] (x, g, a optional)."""
+    ref = x if x is not None else a
+    y = torch.empty(B * HW, C, device=ref.device, dtype=torch.float32)
+    N.check(N.load().icap_chan_affine_f32(_p(x), _p(g), _p(a), float(alpha), B, HW, C, y.data_ptr(), _stream()), "chan_affine")
+    return y
+
+
+def image_dot(x, y, B, HW, C, scale=1.0):
+    out = torch.empty(B, C, device=x.device, dtype=torch.float32)
+    N.check(N.load().icap_image_dot_f32(x.data_ptr(), _p(y), B, HW, C, float(scale), out.data_ptr(), _stream()), "image_dot")
+    return out
+
+
+def dwconv_bwd_data(dy, w, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo):
+    dx = torch.empty(B * H * W, C, device=dy.device, dtype=torch.float32)
+    N.check(N.load().icap_dwconv_bwd_data_f32(dy.data_ptr(), w.data_ptr(), B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, dx.data_ptr(), _stream()),
+            "dwconv_bwd_data")
+    return dx
+
+
+def dwconv_bwd_weight(dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo):
+    lib = N.load()
+    dw = torch.empty(K * K, C, device=dy.device, dtype=torch.float32)
+    ws = _ws(lib.icap_dwconv_bwd_weight_ws_floats(B, Ho, Wo, C, K), dy.device)
+    N.check(lib.icap_dwconv_bwd_weight_f32(dy.data_ptr(), x.data_ptr(), B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, dw.data_ptr(), ws.data_ptr(),
+                                           _stream()), "dwconv_bwd_weight")
+    return dw
+
+
+def im2col(x, B, H, W, C, KH, KW, S, pad_t, pad_l, Ho, Wo):
+    col = torch.empty(B * Ho * Wo, KH * KW * C, device=x.device, dtype=torch.float32)
+    N.check(N.load().icap_im2col_f32(x.data_ptr(), B, H, W, C, KH, KW, S, pad_t, pad_l, Ho, Wo, col.data_ptr(), _stream()), "im2col")
+    return col

@@ -288,3 +288,40 @@ class GradientReducer:
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.handles = []
+
+
+# ---------------------------------------------------------------------------- one training step
+class Trainer:
+    """The loop body of transformer_word_level_bahdnau.py:218-233 (and of the word / char transformer and seq2seq
+    loops, which differ only in the loss call): zero_grad, forward in train mode, loss, backward, optimizer step -
+    with the gradient exchange of data-parallel training between backward and the step when a process group is up.
+
+        trainer = Trainer(model, lr=1e-4, weight_decay=1e-5)          # AdamW as at line 191
+        loss = trainer.step(images, captions, padding_idx)
+
+    ``step`` enqueues everything on the current stream and returns the loss as a device scalar (no host sync).
+    """
+
+    def __init__(self, model, lr=1e-4, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, group=None, bucket_mb=16.0,
+                 loss="compute_loss"):
+        import torch.distributed as dist
+        self.model = model
+        self.opt = AdamW(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.reducer = GradientReducer(self.opt, group=group, bucket_mb=bucket_mb) if dist.is_available() and dist.is_initialized() else None
+        self.loss_kind = loss
+
+    def step(self, images, captions, padding_idx):
+        self.model.train()
+        self.opt.zero_grad()
+        if self.reducer is not None:
+            self.reducer.prepare()
+        predictions = self.model(images, captions)
+        if self.loss_kind == "compute_loss":
+            loss = compute_loss(predictions[:, :-1], captions[:, 1:], padding_idx)
+        else:
+            loss = CrossEntropyLoss(ignore_index=padding_idx)(predictions.reshape(-1, predictions.size(-1)), captions.reshape(-1))
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.opt.step()
+        return loss.detach()

@@ -331,6 +331,29 @@ int icap_att_bwd_f32(const float* u, const float* w, const float* a_w, const flo
 int icap_embedding_bwd_f32(const long long* idx, const float* dy, int ldd, int P, int E, int V, float* dtable,
                            void* stream);
 
+/* ------------------------------------------------------------------ training step: convolutional encoder
+ * Gradients through the EfficientNet-B0 of get_cnn_model (transformer_word_level_bahdnau.py:12-25), which the
+ * reference trains end to end (optimizer over caption_model.parameters(), :191).  NHWC fp32. */
+
+/* y[b,p,c] = x[b,p,c] * g[b][c] + a[b][c] * alpha (x, g, a optional): squeeze-excite gate forward, its input
+ * gradient together with the pooled mean's gradient, global-average-pool backward. */
+int icap_chan_affine_f32(const float* x, const float* g, const float* a, float alpha, int B, int HW, int C, float* y,
+                         void* stream);
+/* out[b][c] = scale * sum_p x[b,p,c] * y[b,p,c] (y NULL: sum of x): gradient of the squeeze-excite gate. */
+int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, void* stream);
+
+/* Depthwise convolution gradients (weights [K*K][C], TF-"same" padding given as pad_t / pad_l). */
+int icap_dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, int C, int K, int S, int pad_t,
+                             int pad_l, int Ho, int Wo, float* dx, void* stream);
+int icap_dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, int W, int C, int K, int S, int pad_t,
+                               int pad_l, int Ho, int Wo, float* dw, float* ws, void* stream);
+long long icap_dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K);
+
+/* col[m][(r*KW+q)*C + c] = x[b, ho*S-pad_t+r, wo*S-pad_l+q, c]: patches of the stem convolution's input, so that
+ * its weight gradient is one icap_gemm_bwd_f32 (a_kmajor = 1) call. */
+int icap_im2col_f32(const float* x, int B, int H, int W, int C, int KH, int KW, int S, int pad_t, int pad_l, int Ho,
+                    int Wo, float* col, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,62 @@ def efficientnet_b0_features(sd, x, p=""):
     return F.adaptive_avg_pool2d(x, 1).flatten(1)
 
 
+def _bn_train(sd, name, x, bufs, eps, momentum=0.01):
+    """Train-mode BatchNorm2d: batch statistics, running statistics in ``bufs`` updated in place."""
+    return F.batch_norm(x, bufs[name + ".running_mean"], bufs[name + ".running_var"], sd[name + ".weight"], sd[name + ".bias"],
+                        training=True, momentum=momentum, eps=eps)
+
+
+def efficientnet_b0_features_train(sd, x, bufs, masks=None, p="", drop_connect_rate=0.2):
+    """Train-mode forward of efficientnet_pytorch's EfficientNet-B0 up to (and including) the dropout in front of
+    ``_fc``: batch-statistic BatchNorm (eps 1e-3, momentum 0.01), drop-connect on the skip blocks with rate
+    0.2 * block_index / 16 (one Bernoulli factor per sample), dropout 0.2 on the pooled feature.
+    ``masks``: {"dc<i>": [B] factors, "cnn_drop": [B, 1280] factors}; a missing key means no dropping.
+    ``bufs``: running statistics (cloned by the caller), updated in place."""
+    m = masks or {}
+    size = 224
+    x = _swish(_bn_train(sd, p + "_bn0", F.conv2d(_same_pad_static(x, 3, 2, size), sd[p + "_conv_stem.weight"], stride=2), bufs, 1e-3))
+    size = -(-size // 2)
+    bi = 0
+    for (r, k, s, e, cin, cout) in _B0:
+        for j in range(r):
+            q = f"{p}_blocks.{bi}."
+            stride = s if j == 0 else 1
+            ci = cin if j == 0 else cout
+            inp = x
+            h = x
+            if e != 1:
+                h = _swish(_bn_train(sd, q + "_bn0", F.conv2d(h, sd[q + "_expand_conv.weight"]), bufs, 1e-3))
+            h = F.conv2d(_same_pad_static(h, k, stride, size), sd[q + "_depthwise_conv.weight"], stride=stride, groups=h.shape[1])
+            h = _swish(_bn_train(sd, q + "_bn1", h, bufs, 1e-3))
+            size = -(-size // stride)
+            sq = F.adaptive_avg_pool2d(h, 1)
+            sq = F.conv2d(_swish(F.conv2d(sq, sd[q + "_se_reduce.weight"], sd[q + "_se_reduce.bias"])),
+                          sd[q + "_se_expand.weight"], sd[q + "_se_expand.bias"])
+            h = torch.sigmoid(sq) * h
+            h = _bn_train(sd, q + "_bn2", F.conv2d(h, sd[q + "_project_conv.weight"]), bufs, 1e-3)
+            if stride == 1 and ci == cout:
+                dc = m.get(f"dc{bi}")
+                if dc is not None and drop_connect_rate * bi / 16 > 0:
+                    h = h * dc.view(-1, 1, 1, 1)
+                h = h + inp
+            x = h
+            bi += 1
+    x = _swish(_bn_train(sd, p + "_bn1", F.conv2d(x, sd[p + "_conv_head.weight"]), bufs, 1e-3))
+    x = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    if m.get("cnn_drop") is not None:
+        x = x * m["cnn_drop"]
+    return x
+
+
+def cnn_model_train(sd, x, bufs, masks=None, p="cnn_model."):
+    """get_cnn_model in train mode: EfficientNet-B0 (train) then Linear(1280, 512)."""
+    bufs0 = {k[len(p + "0."):]: v for k, v in bufs.items() if k.startswith(p + "0.")}
+    sd0 = {k[len(p + "0."):]: v for k, v in sd.items() if k.startswith(p + "0.")}
+    f = efficientnet_b0_features_train(sd0, x, bufs0, masks)
+    return f @ sd[p + "1.weight"].t() + sd[p + "1.bias"]
+
+
 def cnn_model(sd, x, p="cnn_model."):
     """get_cnn_model: EfficientNet-B0 features then Linear(1280, 512) (transformer_word_level.py:19-22)."""
     f = efficientnet_b0_features(sd, x, p + "0.")

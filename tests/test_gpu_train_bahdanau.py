@@ -119,3 +119,54 @@ def test_generated_dropout_is_reproducible_and_scaled():
     b = model.forward_features(feats, caps).detach().clone()
     c = model.forward_features(feats, caps).detach().clone()
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_full_model_training_step_matches_oracle():
+    """Images -> EfficientNet-B0 (train) -> encoder block -> decoder -> compute_loss -> backward, against the CPU
+    oracle with shared dropout / drop-connect masks; then one AdamW step through Trainer."""
+    from image_captioning_amd import transformer_word_level_bahdnau as my_bah
+    from image_captioning_amd.synthetic import seeded_state_dict
+    from image_captioning_amd.training import Trainer, compute_loss
+    from oracle import backbones_ref as BR
+    V, B, T, p = 300, 3, 5, 0.3
+    model = my_bah.build_model(V, dropout=p)
+    sd = seeded_state_dict(model, seed=5)
+    model.load_state_dict(sd)
+    model.to(D).train()
+    g = torch.Generator().manual_seed(9)
+    images = torch.randn(B, 3, 224, 224, generator=g)
+    caps = torch.randint(1, V, (B, T), generator=g)
+
+    def mk(prob, *shape):
+        return (torch.rand(*shape, generator=g) >= prob).float() / (1 - prob)
+    masks = {f"dc{i}": mk(0.2 * i / 16, B) for i in range(16)}
+    masks.update(cnn_drop=mk(0.2, B, 1280), enc_att=mk(p, B, 512), enc_fc1=mk(p, B, 512), enc_fc2=mk(p, B, 512), dec_out=mk(p, B, T, 512))
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    bufs = {k: v.detach().clone() for k, v in sdr.items() if "running" in k}
+    feats_r = BR.cnn_model_train(sdr, images, bufs, masks)
+    enc_bn = {"running_mean": bufs["encoder.fc.3.running_mean"], "running_var": bufs["encoder.fc.3.running_var"]}
+    dec_bn = {"running_mean": bufs["decoder.fc.1.running_mean"], "running_var": bufs["decoder.fc.1.running_var"]}
+    pred_r = TR.bah_train_forward(sdr, feats_r, caps, enc_bn, dec_bn, masks)
+    loss_r = O.compute_loss(pred_r[:, :-1], caps[:, 1:], 0)
+    loss_r.backward()
+
+    gm = {k: v.to(D) for k, v in masks.items()}
+    model.cnn_model.dropout_masks = gm
+    model.encoder.dropout_masks = gm
+    model.decoder.dropout_masks = gm
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-5)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    loss = trainer.step(images.to(D), caps.to(D), 0)
+    assert abs(loss.item() - loss_r.item()) < 2e-3
+    bad = []
+    for name, prm in model.named_parameters():
+        want = sdr[name].grad
+        if want is None:
+            assert torch.equal(prm.detach(), before[name]), name          # no gradient: untouched by the optimizer
+            continue
+        err = (prm.grad.cpu() - want).abs().max().item()
+        if err > 3e-2 * want.abs().max().item() + 2e-5:
+            bad.append((name, err, want.abs().max().item()))
+    assert not bad, bad[:10]
+    moved = sum(int(not torch.equal(prm.detach(), before[n])) for n, prm in model.named_parameters())
+    assert moved > 200

@@ -1,0 +1,91 @@
+"""GPU parity of the EfficientNet-B0 (+ Linear) training-mode forward and hand-written backward against the CPU
+oracle's train-mode restatement with torch autograd (parity unpinned for the backbone: the efficientnet_pytorch
+package is absent, see oracle/backbones_ref.py), and of the CNN-specific gradient kernels against torch."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import backbones_ref as BR
+
+pytestmark = pytest.mark.gpu
+D = "cuda:0"
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed + sum(shape)))
+
+
+@pytest.mark.parametrize("B,H,W,C,K,S", [(2, 14, 14, 48, 3, 1), (2, 15, 15, 24, 5, 2), (3, 8, 8, 16, 3, 2), (1, 7, 7, 64, 5, 1)])
+def test_depthwise_gradients(B, H, W, C, K, S):
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd.backbones import same_pad
+    lo, hi = same_pad(K, S)
+    x = rnd(B, C, H, W, seed=1).requires_grad_(True)
+    w = rnd(C, 1, K, K, seed=2).requires_grad_(True)
+    y = F.conv2d(F.pad(x, (lo, hi, lo, hi)), w, stride=S, groups=C)
+    Ho, Wo = y.shape[2], y.shape[3]
+    dy = rnd(B, C, Ho, Wo, seed=3)
+    y.backward(dy)
+    dy2 = dy.permute(0, 2, 3, 1).contiguous().view(-1, C).to(D)
+    x2 = x.detach().permute(0, 2, 3, 1).contiguous().view(-1, C).to(D)
+    w2 = w.detach().view(C, K * K).t().contiguous().to(D)
+    dx = T.dwconv_bwd_data(dy2, w2, B, H, W, C, K, S, lo, lo, Ho, Wo).view(B, H, W, C).permute(0, 3, 1, 2).cpu()
+    dw = T.dwconv_bwd_weight(dy2, x2, B, H, W, C, K, S, lo, lo, Ho, Wo).t().reshape(C, 1, K, K).cpu()
+    torch.testing.assert_close(dx, x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dw, w.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_channel_affine_and_image_dot():
+    from image_captioning_amd import train_ops as T
+    B, HW, C = 3, 49, 32
+    x, g, a = rnd(B * HW, C, seed=4), rnd(B, C, seed=5), rnd(B, C, seed=6)
+    y = T.chan_affine(x.to(D), g.to(D), a.to(D), 0.5, B, HW, C).cpu()
+    want = x.view(B, HW, C) * g[:, None, :] + 0.5 * a[:, None, :]
+    torch.testing.assert_close(y.view(B, HW, C), want)
+    d = T.image_dot(x.to(D), y.to(D), B, HW, C).cpu()
+    torch.testing.assert_close(d, (x.view(B, HW, C) * y.view(B, HW, C)).sum(1), rtol=1e-4, atol=1e-4)
+
+
+def _cnn():
+    from image_captioning_amd.backbones import get_cnn_model
+    from image_captioning_amd.synthetic import seeded_state_dict
+    m = get_cnn_model()
+    sd = seeded_state_dict(m, seed=11)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+def test_efficientnet_training_forward_backward_matches_oracle():
+    B = 3
+    model, sd = _cnn()
+    model.to(D).train()
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(B, 3, 224, 224, generator=g)
+    masks = {f"dc{i}": (torch.rand(B, generator=g) >= 0.2 * i / 16).float() / (1 - 0.2 * i / 16) for i in range(16)}
+    masks["cnn_drop"] = (torch.rand(B, 1280, generator=g) >= 0.2).float() / 0.8
+    dout = torch.randn(B, 512, generator=g)
+    # oracle
+    sdr = {("cnn_model." + k): v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    bufs = {k: v.detach().clone() for k, v in sdr.items() if "running" in k}
+    out_r = BR.cnn_model_train(sdr, images, bufs, masks)
+    out_r.backward(dout)
+    # HIP
+    model.dropout_masks = {k: v.to(D) for k, v in masks.items()}
+    out = model(images.to(D))
+    out.backward(dout.to(D))
+    torch.testing.assert_close(out.detach().cpu(), out_r.detach(), rtol=2e-3, atol=2e-3)
+    bad = []
+    for name, prm in model.named_parameters():
+        want = sdr["cnn_model." + name].grad
+        got = prm.grad
+        assert got is not None, name
+        # a per-channel constant in front of (1x1 conv ->) train-mode BatchNorm is removed by the mean
+        # subtraction: _bn2.bias and friends have a true gradient of ~0 and hold rounding noise on both sides,
+        # hence the absolute floor
+        err = (got.cpu() - want).abs().max().item()
+        if err > 2e-2 * want.abs().max().item() + 2e-5:
+            bad.append((name, err, want.abs().max().item()))
+    assert not bad, bad[:10]
+    sd_after = model.state_dict()
+    for k in ("0._bn0.running_mean", "0._blocks.5._bn1.running_var", "0._bn1.running_var"):
+        torch.testing.assert_close(sd_after[k].cpu(), bufs["cnn_model." + k], rtol=1e-3, atol=1e-5)

@@ -5,6 +5,11 @@
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --mode train [--batch 64]        # the second half of the metric: training imgs/s
+
+--mode train times the teacher-forced training step of the Bahdanau captioner (EfficientNet-B0 in train mode,
+encoder block, 20-step LSTMCell decoder, masked cross entropy, backward, AdamW; data-parallel with a bucketed
+RCCL all-reduce when launched on N ranks) and prints the same kind of JSON line with unit imgs/s.
 
 A "step" is one pass of the hot path over one batch of --batch images already resident in HBM:
 NCHW fp32 images -> encoder features -> 20 greedy tokens per image (every image decoded as its own
@@ -35,7 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="images per step per GPU")
+    ap.add_argument("--mode", choices=("caption", "train"), default="caption")
+    ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 256 captioning, 64 training)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=384, help="images in the CPU-baseline sample")
@@ -62,7 +68,21 @@ def linear_work(sig):
     return 2.0 * M * K * Nn, 4.0 * (M * K + K * Nn + M * Nn * (2 if has_res else 1))
 
 
-WORK = {"conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work}
+def gemm_work(sig):
+    a, b, c = sig
+    return 2.0 * a * b * c, 4.0 * (a * b + b * c + a * c)
+
+
+WORK = {"conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work,
+        # training-step launches: (flops, algorithmic bytes)
+        "gemm_nn": gemm_work, "gemm_tn": gemm_work,
+        "col_reduce": lambda s: (2.0 * s[1] * s[2], 4.0 * s[1] * s[2] * (2 if s[0] >= 2 else 1)),
+        "scale_bias_act": lambda s: (2.0 * s[0] * s[1], 4.0 * s[0] * s[1] * (3 if s[2] else 2)),
+        "bn_act_bwd": lambda s: (8.0 * s[0] * s[1], 4.0 * s[0] * s[1] * 3),
+        "chan_affine": lambda s: (2.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * (2 if s[3] else 1)),
+        "image_dot": lambda s: (2.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * (2 if s[3] else 1)),
+        "dwconv_bwd_data": lambda s: (2.0 * s[0] * s[6] * s[7] * s[3] * s[4] * s[4], 4.0 * s[3] * s[0] * (s[1] * s[2] + s[6] * s[7])),
+        "dwconv_bwd_weight": lambda s: (2.0 * s[0] * s[6] * s[7] * s[3] * s[4] * s[4], 4.0 * s[3] * s[0] * (s[1] * s[2] + s[6] * s[7]))}
 
 
 def main():
@@ -83,19 +103,34 @@ def main():
 
     from image_captioning_amd import ops
     from image_captioning_amd import transformer_word_level as twl
-    from image_captioning_amd.synthetic import seeded_state_dict, synthetic_images
+    from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images
 
-    model = twl.build_model(VOCAB)
-    model.load_state_dict(seeded_state_dict(model, seed=52))
-    model = model.eval().to(dev)
-    B = args.batch
+    train = args.mode == "train"
+    B = args.batch or (64 if train else 256)
     # synthetic images: a small seeded pool tiled to the batch (content does not change the work)
     pool = synthetic_images(min(B, 32), seed=1234 + rank)
     images = pool.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
+    if train:
+        from image_captioning_amd import transformer_word_level_bahdnau as bah
+        from image_captioning_amd._bah_train import DropoutState
+        from image_captioning_amd.training import Trainer
+        model = bah.build_model(VOCAB, dropout=0.3)                       # transformer_word_level_bahdnau.py:171,183-188
+        model.load_state_dict(seeded_state_dict(model, seed=52))
+        model = model.to(dev)
+        DropoutState.manual_seed(1000 + rank)                             # dropout differs per rank, weights do not
+        trainer = Trainer(model, lr=1e-4, weight_decay=1e-5)              # :191
+        caps = synthetic_captions(B, CAPTION_LEN, VOCAB, 2, 3, 0, seed=77 + rank).to(dev)
 
-    def step():
-        feats = model.cnn_model(images)
-        return model.greedy_ids_from_features(feats, CAPTION_LEN)
+        def step():
+            return trainer.step(images, caps, 0)
+    else:
+        model = twl.build_model(VOCAB)
+        model.load_state_dict(seeded_state_dict(model, seed=52))
+        model = model.eval().to(dev)
+
+        def step():
+            feats = model.cnn_model(images)
+            return model.greedy_ids_from_features(feats, CAPTION_LEN)
 
     if args.breakdown:
         breakdown(torch, ops, step, B)
@@ -148,7 +183,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert ids.shape == (B, CAPTION_LEN)
+    assert train or ids.shape == (B, CAPTION_LEN)
 
     if rank == 0:
         captions = world * B * args.steps
@@ -164,19 +199,26 @@ def main():
         roof["traffic"] = None
         roof["kernel"] = f"{dom['name']}{list(dom['sig'])}"
         roof["avg_launch_ms"] = dom_ms
+        if train:
+            workload = ("transformer_word_level_bahdnau: teacher-forced training step (EfficientNet-B0 train mode + encoder block + "
+                        "Bahdanau LSTMCell decoder, compute_loss, backward, AdamW), fp32 (BASELINE configs[2] names bf16: not built yet)")
+            par = f"data-parallel x{world}, bucketed all-reduce of {sum(p.numel() for p in model.parameters()) * 4 / 1e6:.1f} MB of gradients" \
+                if world > 1 else "single GPU, no collective"
+        else:
+            workload = ("transformer_word_level: EfficientNet-B0 encoder + word-level transformer decoder, "
+                        "batched greedy captioning (BASELINE configs[1])")
+            par = f"image-sharded x{world}, no collective"
         out = {
             "metric": "captions/sec greedy + train imgs/sec, 224px food imgs, 1/2/4/8 MI355X",
-            "value": captions / elapsed, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "transformer_word_level: EfficientNet-B0 encoder + word-level transformer decoder, "
-                                   "batched greedy captioning (BASELINE configs[1])",
-                       "images_per_step_per_gpu": B, "image": "3x224x224 fp32", "caption_tokens": CAPTION_LEN, "vocab": VOCAB,
-                       "weights": "seeded random init", "parallelism": f"image-sharded x{world}, no collective"},
+            "value": captions / elapsed, "unit": "imgs/s" if train else "captions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "images_per_step_per_gpu": B, "image": "3x224x224 fp32", "caption_tokens": CAPTION_LEN,
+                       "vocab": VOCAB, "weights": "seeded random init", "parallelism": par},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(torch, model, args.cpu_sample)
+            out["cpu_baseline"] = cpu_train_baseline(torch, model, min(B, 12)) if train else cpu_baseline(torch, model, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -230,6 +272,39 @@ def cpu_baseline(torch, model, n):
     return {"value": n / dt, "unit": "captions/s", "cores": threads, "kind": "port",
             "sample": f"{n} synthetic 224x224 images: oracle EfficientNet-B0 (batches of 16) + per-image prefix-re-run greedy decode, "
                       f"{CAPTION_LEN} tokens, fp32, torch CPU with {threads} threads, {dt:.1f} s"}
+
+
+def cpu_train_baseline(torch, model, B):
+    """The CPU oracle's training step (train-mode forward with torch autograd backward and torch.optim.AdamW) on the
+    host cores: one warm-up and two timed steps at the reference's batch size."""
+    from image_captioning_amd.synthetic import synthetic_captions, synthetic_images
+    from oracle import backbones_ref as BR, torch_ref as R, train_ref as TR
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    params = {k: v.float().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    bufs = {k: v.float() for k, v in sd.items() if "running" in k}
+    full = dict(sd)
+    full.update(params)
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-4, weight_decay=1e-5)
+    imgs = synthetic_images(B, seed=99)
+    caps = synthetic_captions(B, CAPTION_LEN, VOCAB, 2, 3, 0, seed=98)
+    threads = torch.get_num_threads()
+    enc_bn = {"running_mean": bufs["encoder.fc.3.running_mean"], "running_var": bufs["encoder.fc.3.running_var"]}
+    dec_bn = {"running_mean": bufs["decoder.fc.1.running_mean"], "running_var": bufs["decoder.fc.1.running_var"]}
+
+    def one():
+        opt.zero_grad()
+        feats = BR.cnn_model_train(full, imgs, bufs, None)
+        pred = TR.bah_train_forward(full, feats, caps, enc_bn, dec_bn, None)
+        R.compute_loss(pred[:, :-1], caps[:, 1:], 0).backward()
+        opt.step()
+    one()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        one()
+    dt = (time.perf_counter() - t0) / 2
+    return {"value": B / dt, "unit": "imgs/s", "cores": threads, "kind": "port",
+            "sample": f"2 training steps of {B} synthetic images x {CAPTION_LEN} tokens (dropout masks omitted), oracle forward + torch "
+                      f"autograd + torch.optim.AdamW, fp32, torch CPU with {threads} threads, {dt:.1f} s per step"}
 
 
 if __name__ == "__main__":

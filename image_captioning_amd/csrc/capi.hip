@@ -77,7 +77,8 @@ int att_bwd_f32(const float*, const float*, const float*, const float*, const fl
 int embedding_bwd_f32(const long long*, const float*, int, int, int, int, float*, hipStream_t);
 
 int chan_affine_f32(const float*, const float*, const float*, float, int, int, int, float*, hipStream_t);
-int image_dot_f32(const float*, const float*, int, int, int, float, float*, hipStream_t);
+int image_dot_f32(const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
+long long image_dot_ws_floats(int, int, int);
 int dwconv_bwd_data_f32(const float*, const float*, int, int, int, int, int, int, int, int, int, int, float*, hipStream_t);
 int dwconv_bwd_weight_f32(const float*, const float*, int, int, int, int, int, int, int, int, int, int, float*, float*, hipStream_t);
 long long dwconv_bwd_weight_ws_floats(int, int, int, int, int);
@@ -467,9 +468,10 @@ int icap_chan_affine_f32(const float* x, const float* g, const float* a, float a
     return chan_affine_f32(x, g, a, alpha, B, HW, C, y, (hipStream_t)stream);
 }
 
-int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, void* stream) {
-    return image_dot_f32(x, y, B, HW, C, scale, out, (hipStream_t)stream);
+int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, float* ws, void* stream) {
+    return image_dot_f32(x, y, B, HW, C, scale, out, ws, (hipStream_t)stream);
 }
+long long icap_image_dot_ws_floats(int B, int HW, int C) { return image_dot_ws_floats(B, HW, C); }
 
 int icap_dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, int C, int K, int S, int pad_t, int pad_l, int Ho,
                              int Wo, float* dx, void* stream) {

@@ -38,29 +38,77 @@ int chan_affine_f32(const float* x, const float* g, const float* a, float alpha,
     return launch_status("chan_affine");
 }
 
-// out[b][c] = scale * sum_p x[b,p,c] * y[b,p,c]  (y == null: sum of x).  One workgroup per (64 channels, image);
-// the four row lanes of a workgroup are added in a fixed order.
+// out[b][c] = scale * sum_p x[b,p,c] * y[b,p,c]  (y == null: sum of x).  TX threads span 4*TX adjacent channels
+// (one float4 each), 256/TX threads share the rows of one chunk of one image; chunk partials go to
+// part[b][chunk][C] and image_dot_finish_kernel adds them in order.
+template <int TX>
 __global__ __launch_bounds__(256) void image_dot_kernel(const float* __restrict__ x, const float* __restrict__ y, int HW, int C,
-                                                        float scale, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx, b = blockIdx.y;
-    float s = 0.f;
+                                                        int rows_per_chunk, float* __restrict__ part) {
+    constexpr int TY = 256 / TX;
+    __shared__ float4 red[TY][TX];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * 4;
+    const int chunk = blockIdx.y, nchunks = gridDim.y, b = blockIdx.z;
+    const int p_lo = chunk * rows_per_chunk, p_hi = min(HW, p_lo + rows_per_chunk);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C) {
         const size_t base = (size_t)b * HW * C + c;
-        for (int p = ry; p < HW; p += 4) {
-            const float xv = x[base + (size_t)p * C];
-            s += y ? xv * y[base + (size_t)p * C] : xv;
+        for (int p = p_lo + ty; p < p_hi; p += TY) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
+            if (y) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + base + (size_t)p * C);
+                s.x = fmaf(xv.x, yv.x, s.x); s.y = fmaf(xv.y, yv.y, s.y); s.z = fmaf(xv.z, yv.z, s.z); s.w = fmaf(xv.w, yv.w, s.w);
+            } else {
+                s.x += xv.x; s.y += xv.y; s.z += xv.z; s.w += xv.w;
+            }
         }
     }
-    red[ry][cx] = s;
+    red[ty][tx] = s;
     __syncthreads();
-    if (ry == 0 && c < C) out[(size_t)b * C + c] = (((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx]) * scale;
+    if (ty == 0 && c < C) {
+        float4 t = red[0][tx];
+        for (int k = 1; k < TY; ++k) { const float4 o = red[k][tx]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        *reinterpret_cast<float4*>(part + ((size_t)b * nchunks + chunk) * C + c) = t;
+    }
 }
 
-int image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, hipStream_t st) {
-    if (!x || !out || B <= 0 || HW <= 0 || C <= 0) { set_error("image_dot: bad arguments"); return ICAP_ERR_ARG; }
-    hipLaunchKernelGGL(image_dot_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, y, HW, C, scale, out);
+__global__ __launch_bounds__(256) void image_dot_finish_kernel(const float* __restrict__ part, int nchunks, int C, int total,
+                                                               float scale, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // b * C + c
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += part[((size_t)b * nchunks + k) * C + c];
+    out[i] = s * scale;
+}
+
+static int image_dot_rows(int B, int HW, int C) {
+    const int col_blocks = (C + 255) / 256;
+    long long want = 1024 / ((long long)B * col_blocks);
+    if (want < 1) want = 1;
+    long long rows = (HW + want - 1) / want;
+    if (rows < 32) rows = 32;
+    return (int)rows;
+}
+
+long long image_dot_ws_floats(int B, int HW, int C) {
+    const int rows = image_dot_rows(B, HW, C);
+    return (long long)B * ((HW + rows - 1) / rows) * C;
+}
+
+int image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, float* ws, hipStream_t st) {
+    if (!x || !out || !ws || B <= 0 || HW <= 0 || C <= 0) { set_error("image_dot: bad arguments"); return ICAP_ERR_ARG; }
+    if (C % 4 || !aligned16(x) || (y && !aligned16(y)) || !aligned16(ws)) { set_error("image_dot: C %% 4 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
+    const int rows = image_dot_rows(B, HW, C), nchunks = (HW + rows - 1) / rows, c4 = C / 4;
+    const int tx = c4 <= 8 ? 8 : (c4 <= 16 ? 16 : (c4 <= 32 ? 32 : 64));
+    const dim3 grid((c4 + tx - 1) / tx, nchunks, B);
+    switch (tx) {
+        case 8: hipLaunchKernelGGL(image_dot_kernel<8>, grid, dim3(256), 0, st, x, y, HW, C, rows, ws); break;
+        case 16: hipLaunchKernelGGL(image_dot_kernel<16>, grid, dim3(256), 0, st, x, y, HW, C, rows, ws); break;
+        case 32: hipLaunchKernelGGL(image_dot_kernel<32>, grid, dim3(256), 0, st, x, y, HW, C, rows, ws); break;
+        default: hipLaunchKernelGGL(image_dot_kernel<64>, grid, dim3(256), 0, st, x, y, HW, C, rows, ws); break;
+    }
+    hipLaunchKernelGGL(image_dot_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, ws, nchunks, C, B * C, scale, out);
     return launch_status("image_dot");
 }
 
@@ -114,59 +162,91 @@ int dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, in
 
 // ---------------------------------------------------------------- depthwise convolution, weight gradient
 // dw[r*K+q][c] = sum over (b,ho,wo) of dy[b,ho,wo,c] * x[b, ho*S - pad_t + r, wo*S - pad_l + q, c].
-// A workgroup owns 64 channels and a chunk of DWW_ROWS output pixels; partials [chunk][K*K][C] are added in
-// order by dwconv_wgrad_finish_kernel.
-constexpr int DWW_ROWS = 1024;
-
-template <int KK>
+// TX threads span 4*TX adjacent channels (one float4 each, K*K float4 accumulators), 256/TX threads share a chunk
+// of output pixels; partials [chunk][K*K][C] are added in order by dwconv_wgrad_finish_kernel.
+template <int KK, int TX>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B,
                                                                 int H, int W, int C, int K, int S, int pad_t, int pad_l, int Ho,
-                                                                int Wo, float* __restrict__ part) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+                                                                int Wo, int rows_per_chunk, float* __restrict__ part) {
+    constexpr int TY = 256 / TX;
+    __shared__ float4 red[TY][TX];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * 4;
     const int chunk = blockIdx.y;
     const long long M = (long long)B * Ho * Wo;
-    const long long lo = (long long)chunk * DWW_ROWS, hi = min(M, lo + DWW_ROWS);
-    float acc[KK];
+    const long long lo = (long long)chunk * rows_per_chunk, hi = min(M, lo + rows_per_chunk);
+    float4 acc[KK];
 #pragma unroll
-    for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+    for (int t = 0; t < KK; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C) {
-        for (long long m = lo + ry; m < hi; m += 4) {
+        for (long long m = lo + ty; m < hi; m += TY) {
             const int wo = (int)(m % Wo);
             const long long t2 = m / Wo;
             const int ho = (int)(t2 % Ho);
             const int b = (int)(t2 / Ho);
-            const float d = dy[(size_t)m * C + c];
+            const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)m * C + c);
 #pragma unroll
             for (int t = 0; t < KK; ++t) {
                 const int r = t / K, q = t - r * K;
                 const int hi2 = ho * S - pad_t + r, wi2 = wo * S - pad_l + q;
-                if ((unsigned)hi2 < (unsigned)H && (unsigned)wi2 < (unsigned)W)
-                    acc[t] = fmaf(d, x[(((size_t)b * H + hi2) * W + wi2) * C + c], acc[t]);
+                if ((unsigned)hi2 < (unsigned)H && (unsigned)wi2 < (unsigned)W) {
+                    const float4 xv = *reinterpret_cast<const float4*>(x + (((size_t)b * H + hi2) * W + wi2) * C + c);
+                    acc[t].x = fmaf(d.x, xv.x, acc[t].x); acc[t].y = fmaf(d.y, xv.y, acc[t].y);
+                    acc[t].z = fmaf(d.z, xv.z, acc[t].z); acc[t].w = fmaf(d.w, xv.w, acc[t].w);
+                }
             }
         }
     }
     for (int t = 0; t < KK; ++t) {
-        red[ry][cx] = acc[t];
+        red[ty][tx] = acc[t];
         __syncthreads();
-        if (ry == 0 && c < C) part[((size_t)chunk * KK + t) * C + c] = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
+        if (ty == 0 && c < C) {
+            float4 s = red[0][tx];
+            for (int k = 1; k < TY; ++k) { const float4 o = red[k][tx]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+            *reinterpret_cast<float4*>(part + ((size_t)chunk * KK + t) * C + c) = s;
+        }
         __syncthreads();
     }
 }
 
+// 64 outputs per workgroup, four lanes per output each adding every fourth chunk (fixed order)
 __global__ __launch_bounds__(256) void dwconv_wgrad_finish_kernel(const float* __restrict__ part, int nchunks, int n,
                                                                   float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ky = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cx;
     float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * n + i];
-    out[i] = s;
+    if (i < n)
+        for (int k = ky; k < nchunks; k += 4) s += part[(size_t)k * n + i];
+    red[ky][cx] = s;
+    __syncthreads();
+    if (ky == 0 && i < n) out[i] = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
+}
+
+static int dww_rows(long long M, int C) {
+    const int col_blocks = (C + 255) / 256;
+    long long want = 512 / col_blocks;
+    if (want < 1) want = 1;
+    long long rows = (M + want - 1) / want;
+    if (rows < 32) rows = 32;
+    return (int)rows;
 }
 
 long long dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K) {
     const long long M = (long long)B * Ho * Wo;
-    return ((M + DWW_ROWS - 1) / DWW_ROWS) * (long long)K * K * C;
+    const int rows = dww_rows(M, C);
+    return ((M + rows - 1) / rows) * (long long)K * K * C;
+}
+
+template <int KK>
+static void dww_launch(int tx, dim3 grid, hipStream_t st, const float* dy, const float* x, int B, int H, int W, int C, int K, int S,
+                       int pad_t, int pad_l, int Ho, int Wo, int rows, float* ws) {
+    switch (tx) {
+        case 8: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KK, 8>), grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws); break;
+        case 16: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KK, 16>), grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws); break;
+        case 32: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KK, 32>), grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws); break;
+        default: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KK, 64>), grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws); break;
+    }
 }
 
 int dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, int W, int C, int K, int S, int pad_t, int pad_l, int Ho,
@@ -176,13 +256,17 @@ int dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, int W, 
         return ICAP_ERR_ARG;
     }
     if (K != 3 && K != 5) { set_error("dwconv_bwd_weight: kernel size %d not supported (3 or 5)", K); return ICAP_ERR_ARG; }
+    if (C % 4 || !aligned16(dy) || !aligned16(x) || !aligned16(ws)) { set_error("dwconv_bwd_weight: C %% 4 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
     const long long M = (long long)B * Ho * Wo;
-    const int nchunks = (int)((M + DWW_ROWS - 1) / DWW_ROWS);
-    const dim3 grid((C + 63) / 64, nchunks);
-    if (K == 3) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<9>, grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, ws);
-    else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<25>, grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, ws);
+    const int rows = dww_rows(M, C);
+    const int nchunks = (int)((M + rows - 1) / rows);
+    const int c4 = C / 4;
+    const int tx = c4 <= 8 ? 8 : (c4 <= 16 ? 16 : (c4 <= 32 ? 32 : 64));
+    const dim3 grid((c4 + tx - 1) / tx, nchunks);
+    if (K == 3) dww_launch<9>(tx, grid, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws);
+    else dww_launch<25>(tx, grid, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws);
     const int n = K * K * C;
-    hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, nchunks, n, dw);
+    hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3((n + 63) / 64), dim3(256), 0, st, ws, nchunks, n, dw);
     return launch_status("dwconv_bwd_weight");
 }
 

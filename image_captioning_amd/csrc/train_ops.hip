@@ -76,21 +76,117 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     }
 }
 
-// out1[c] = scale * sum_chunks part[chunk][c] (+ out1[c] when accumulate); same for the second plane
-__global__ __launch_bounds__(256) void col_finish_kernel(const float* __restrict__ part, int nchunks, int C, int planes,
-                                                         float scale, int accumulate, float* __restrict__ out1,
-                                                         float* __restrict__ out2) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    for (int pl = 0; pl < planes; ++pl) {
-        float s = 0.f;
-        for (int k = 0; k < nchunks; ++k) s += part[(size_t)(pl * nchunks + k) * C + c];
-        float* o = pl == 0 ? out1 : out2;
-        o[c] = (accumulate ? o[c] : 0.f) + s * scale;
+// The same reduction for matrices whose rows can be read 16 bytes at a time (C % 4 == 0, row strides % 4 == 0):
+// TX threads span 4*TX adjacent columns with one float4 each and 256/TX threads share the chunk's rows, so a
+// wave reads whole contiguous rows whatever the channel count (16 ... 1152 in EfficientNet-B0); the row lanes
+// meet in LDS in a fixed order.
+template <int MODE, int TX>
+__global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __restrict__ a, int lda, const float* __restrict__ x,
+                                                              int ldx, const float* __restrict__ v1, const float* __restrict__ v2,
+                                                              const float* __restrict__ v3, const float* __restrict__ v4,
+                                                              const float* __restrict__ r1, const float* __restrict__ r2, int act,
+                                                              int M, int C, int rows_per_chunk, float* __restrict__ part) {
+    constexpr int TY = 256 / TX;
+    __shared__ float4 red[2][TY][TX];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * 4;
+    const int chunk = blockIdx.y, nchunks = gridDim.y;
+    const int r_lo = chunk * rows_per_chunk, r_hi = min(M, r_lo + rows_per_chunk);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (c < C) {
+        float4 m = s1, rs = s1, sc = s1, bi = s1;
+        if (MODE == COL_SQDEV || MODE == COL_BN_BWD) m = *reinterpret_cast<const float4*>(v1 + c);
+        if (MODE == COL_BN_BWD) {
+            rs = *reinterpret_cast<const float4*>(v2 + c);
+            sc = *reinterpret_cast<const float4*>(v3 + c);
+            bi = *reinterpret_cast<const float4*>(v4 + c);
+        }
+        for (int r = r_lo + ty; r < r_hi; r += TY) {
+            const float4 av = *reinterpret_cast<const float4*>(a + (size_t)r * lda + c);
+            if (MODE == COL_SUM) {
+                s1.x += av.x; s1.y += av.y; s1.z += av.z; s1.w += av.w;
+            } else if (MODE == COL_SQDEV) {
+                const float dx = av.x - m.x, dy = av.y - m.y, dz = av.z - m.z, dw = av.w - m.w;
+                s1.x += dx * dx; s1.y += dy * dy; s1.z += dz * dz; s1.w += dw * dw;
+            } else if (MODE == COL_BN_BWD) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+                const float g0 = av.x * act_grad(fmaf(xv.x, sc.x, bi.x), act), g1 = av.y * act_grad(fmaf(xv.y, sc.y, bi.y), act);
+                const float g2 = av.z * act_grad(fmaf(xv.z, sc.z, bi.z), act), g3 = av.w * act_grad(fmaf(xv.w, sc.w, bi.w), act);
+                s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
+                s2.x += g0 * ((xv.x - m.x) * rs.x); s2.y += g1 * ((xv.y - m.y) * rs.y);
+                s2.z += g2 * ((xv.z - m.z) * rs.z); s2.w += g3 * ((xv.w - m.w) * rs.w);
+            } else {
+                const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+                const float mr = r1[r], rr = r2[r];
+                s1.x += av.x; s1.y += av.y; s1.z += av.z; s1.w += av.w;
+                s2.x += av.x * ((xv.x - mr) * rr); s2.y += av.y * ((xv.y - mr) * rr);
+                s2.z += av.z * ((xv.z - mr) * rr); s2.w += av.w * ((xv.w - mr) * rr);
+            }
+        }
+    }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int pl = 0; pl < (MODE >= COL_BN_BWD ? 2 : 1); ++pl) {
+            float4 t = red[pl][0][tx];
+            for (int k = 1; k < TY; ++k) { const float4 o = red[pl][k][tx]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            *reinterpret_cast<float4*>(part + (size_t)(pl * nchunks + chunk) * C + c) = t;
+        }
     }
 }
 
-long long col_reduce_ws_floats(int M, int C) { return 2LL * ((M + COL_ROWS - 1) / COL_ROWS) * C; }
+// out1[c] = scale * sum_chunks part[chunk][c] (+ out1[c] when accumulate); same for the second plane.
+// 64 columns per workgroup; four lanes per column each add every fourth chunk and meet in LDS, so the chain of
+// dependent loads is a quarter as long and the order of additions is still fixed.
+__global__ __launch_bounds__(256) void col_finish_kernel(const float* __restrict__ part, int nchunks, int C, int planes,
+                                                         float scale, int accumulate, float* __restrict__ out1,
+                                                         float* __restrict__ out2) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ky = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    for (int pl = 0; pl < planes; ++pl) {
+        float s = 0.f;
+        if (c < C)
+            for (int k = ky; k < nchunks; k += 4) s += part[(size_t)(pl * nchunks + k) * C + c];
+        red[ky][cx] = s;
+        __syncthreads();
+        if (ky == 0 && c < C) {
+            float* o = pl == 0 ? out1 : out2;
+            const float t = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
+            o[c] = (accumulate ? o[c] : 0.f) + t * scale;
+        }
+        __syncthreads();
+    }
+}
+
+// rows per chunk: a few hundred workgroups in flight for tall matrices, at least 64 rows each
+static int col_rows_per_chunk(int M, int C) {
+    const int col_blocks = (C + 255) / 256 > 0 ? (C + 255) / 256 : 1;
+    long long want_chunks = 512 / col_blocks;
+    if (want_chunks < 1) want_chunks = 1;
+    long long rows = (M + want_chunks - 1) / want_chunks;
+    if (rows < 64) rows = 64;
+    return (int)rows;
+}
+
+long long col_reduce_ws_floats(int M, int C) {
+    const int rpc_vec = col_rows_per_chunk(M, C);
+    const long long chunks_vec = (M + rpc_vec - 1) / rpc_vec, chunks_scalar = (M + COL_ROWS - 1) / COL_ROWS;
+    return 2LL * (chunks_vec > chunks_scalar ? chunks_vec : chunks_scalar) * C;
+}
+
+template <int MODE>
+static void col_launch_vec(int tx, dim3 grid, hipStream_t st, const float* a, int lda, const float* x, int ldx, const float* v1,
+                           const float* v2, const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C,
+                           int rpc, float* ws) {
+    switch (tx) {
+        case 8: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 8>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+        case 16: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 16>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+        case 32: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 32>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+        default: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 64>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+    }
+}
 
 int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, const float* v1, const float* v2,
                    const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C, float scale,
@@ -99,15 +195,32 @@ int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, c
     if (mode == COL_SQDEV && !v1) { set_error("col_reduce: mean required"); return ICAP_ERR_ARG; }
     if (mode == COL_BN_BWD && (!x || !v1 || !v2 || !v3 || !v4 || !out2 || ldx < C)) { set_error("col_reduce: BatchNorm operands required"); return ICAP_ERR_ARG; }
     if (mode == COL_LN_BWD && (!x || !r1 || !r2 || !out2 || ldx < C)) { set_error("col_reduce: LayerNorm operands required"); return ICAP_ERR_ARG; }
-    const int nchunks = (M + COL_ROWS - 1) / COL_ROWS;
-    const dim3 grid((C + 63) / 64, nchunks);
-    switch (mode) {
-        case COL_SUM: hipLaunchKernelGGL(col_partial_kernel<COL_SUM>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
-        case COL_SQDEV: hipLaunchKernelGGL(col_partial_kernel<COL_SQDEV>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
-        case COL_BN_BWD: hipLaunchKernelGGL(col_partial_kernel<COL_BN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
-        default: hipLaunchKernelGGL(col_partial_kernel<COL_LN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+    const bool vec = (C % 4 == 0) && (lda % 4 == 0) && aligned16(a) && (!x || ((ldx % 4 == 0) && aligned16(x))) &&
+                     (!v1 || aligned16(v1)) && (!v2 || aligned16(v2)) && (!v3 || aligned16(v3)) && (!v4 || aligned16(v4)) && aligned16(ws);
+    int nchunks;
+    if (vec) {
+        const int c4 = C / 4;
+        const int tx = c4 <= 8 ? 8 : (c4 <= 16 ? 16 : (c4 <= 32 ? 32 : 64));
+        const int rpc = col_rows_per_chunk(M, C);
+        nchunks = (M + rpc - 1) / rpc;
+        const dim3 grid((c4 + tx - 1) / tx, nchunks);
+        switch (mode) {
+            case COL_SUM: col_launch_vec<COL_SUM>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+            case COL_SQDEV: col_launch_vec<COL_SQDEV>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+            case COL_BN_BWD: col_launch_vec<COL_BN_BWD>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+            default: col_launch_vec<COL_LN_BWD>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+        }
+    } else {
+        nchunks = (M + COL_ROWS - 1) / COL_ROWS;
+        const dim3 grid((C + 63) / 64, nchunks);
+        switch (mode) {
+            case COL_SUM: hipLaunchKernelGGL(col_partial_kernel<COL_SUM>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+            case COL_SQDEV: hipLaunchKernelGGL(col_partial_kernel<COL_SQDEV>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+            case COL_BN_BWD: hipLaunchKernelGGL(col_partial_kernel<COL_BN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+            default: hipLaunchKernelGGL(col_partial_kernel<COL_LN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+        }
     }
-    hipLaunchKernelGGL(col_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, nchunks, C, mode >= COL_BN_BWD ? 2 : 1, scale, accumulate, out1, out2);
+    hipLaunchKernelGGL(col_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, st, ws, nchunks, C, mode >= COL_BN_BWD ? 2 : 1, scale, accumulate, out1, out2);
     return launch_status("col_reduce");
 }
 

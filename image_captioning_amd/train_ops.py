@@ -9,7 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _native as N
-from .ops import ACT_NONE, _ck, _stream
+from .ops import ACT_NONE, _Span, _ck, _stream
 
 COL_SUM, COL_SQDEV, COL_BN_BWD, COL_LN_BWD = 0, 1, 2, 3
 
@@ -42,8 +42,10 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, a
         accumulate = False
     lib = N.load()
     ws = _ws(lib.icap_gemm_bwd_ws_floats(M, Nn, K, int(accumulate)), a.device)
+    span = _Span("gemm_nn", (M, K, Nn))
     N.check(lib.icap_gemm_bwd_f32(a.data_ptr(), a.stride(0), 0, b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, Nn, K,
                                   int(accumulate), _p(ws), _stream()), "gemm_nn")
+    span.done()
     return out
 
 
@@ -59,8 +61,10 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, a
         accumulate = False
     lib = N.load()
     ws = _ws(lib.icap_gemm_bwd_ws_floats(M, Nn, K, int(accumulate)), a.device)
+    span = _Span("gemm_tn", (K, M, Nn))
     N.check(lib.icap_gemm_bwd_f32(a.data_ptr(), a.stride(0), 1, b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, Nn, K,
                                   int(accumulate), _p(ws), _stream()), "gemm_tn")
+    span.done()
     return out
 
 
@@ -78,9 +82,11 @@ def col_reduce(mode: int, a, x=None, v1=None, v2=None, v3=None, v4=None, r1=None
         out2 = torch.empty(C, device=dev, dtype=torch.float32)
     lib = N.load()
     ws = _ws(lib.icap_col_reduce_ws_floats(M, C), dev)
+    span = _Span("col_reduce", (mode, M, C))
     N.check(lib.icap_col_reduce_f32(mode, a.data_ptr(), a.stride(0), _p(x), x.stride(0) if x is not None else 0, _p(v1), _p(v2), _p(v3),
                                     _p(v4), _p(r1), _p(r2), act, M, C, float(scale), int(accumulate), out1.data_ptr(), _p(out2),
                                     ws.data_ptr(), _stream()), "col_reduce")
+    span.done()
     return out1, out2
 
 
@@ -109,8 +115,10 @@ def scale_bias_act(x, s=None, b=None, act=ACT_NONE, res=None, out=None):
     M, C = x.shape
     if out is None:
         out = torch.empty(M, C, device=x.device, dtype=torch.float32)
+    span = _Span("scale_bias_act", (M, C, res is not None))
     N.check(N.load().icap_scale_bias_act_f32(x.data_ptr(), x.stride(0), _p(s), _p(b), _p(res), res.stride(0) if res is not None else 0,
                                              act, M, C, out.data_ptr(), out.stride(0), _stream()), "scale_bias_act")
+    span.done()
     return out
 
 
@@ -120,9 +128,11 @@ def batchnorm_act_bwd(dy, x, saved, act=ACT_NONE, affine=True):
     M, C = x.shape
     dbeta, dgamma = col_reduce(COL_BN_BWD, dy, x=x, v1=mean, v2=rstd, v3=s, v4=b, act=act)
     dx = torch.empty(M, C, device=x.device, dtype=torch.float32)
+    span = _Span("bn_act_bwd", (M, C))
     N.check(N.load().icap_bn_act_bwd_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), s.data_ptr(), b.data_ptr(),
                                          mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), act, M, C,
                                          dx.data_ptr(), dx.stride(0), _stream()), "bn_act_bwd")
+    span.done()
     return dx, dgamma, dbeta
 
 
@@ -216,20 +226,28 @@ def chan_affine(x, g, a, alpha, B, HW, C):
     """y[b,p,c] = x*g[b][c] + a[b][c]*alpha over an NHWC tensor viewed as [B*HW, C] (x, g, a optional)."""
     ref = x if x is not None else a
     y = torch.empty(B * HW, C, device=ref.device, dtype=torch.float32)
+    span = _Span("chan_affine", (B, HW, C, x is not None))
     N.check(N.load().icap_chan_affine_f32(_p(x), _p(g), _p(a), float(alpha), B, HW, C, y.data_ptr(), _stream()), "chan_affine")
+    span.done()
     return y
 
 
 def image_dot(x, y, B, HW, C, scale=1.0):
     out = torch.empty(B, C, device=x.device, dtype=torch.float32)
-    N.check(N.load().icap_image_dot_f32(x.data_ptr(), _p(y), B, HW, C, float(scale), out.data_ptr(), _stream()), "image_dot")
+    lib = N.load()
+    ws = _ws(lib.icap_image_dot_ws_floats(B, HW, C), x.device)
+    span = _Span("image_dot", (B, HW, C, y is not None))
+    N.check(lib.icap_image_dot_f32(x.data_ptr(), _p(y), B, HW, C, float(scale), out.data_ptr(), ws.data_ptr(), _stream()), "image_dot")
+    span.done()
     return out
 
 
 def dwconv_bwd_data(dy, w, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo):
     dx = torch.empty(B * H * W, C, device=dy.device, dtype=torch.float32)
+    span = _Span("dwconv_bwd_data", (B, H, W, C, K, S, Ho, Wo))
     N.check(N.load().icap_dwconv_bwd_data_f32(dy.data_ptr(), w.data_ptr(), B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, dx.data_ptr(), _stream()),
             "dwconv_bwd_data")
+    span.done()
     return dx
 
 
@@ -237,8 +255,10 @@ def dwconv_bwd_weight(dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo):
     lib = N.load()
     dw = torch.empty(K * K, C, device=dy.device, dtype=torch.float32)
     ws = _ws(lib.icap_dwconv_bwd_weight_ws_floats(B, Ho, Wo, C, K), dy.device)
+    span = _Span("dwconv_bwd_weight", (B, H, W, C, K, S, Ho, Wo))
     N.check(lib.icap_dwconv_bwd_weight_f32(dy.data_ptr(), x.data_ptr(), B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, dw.data_ptr(), ws.data_ptr(),
                                            _stream()), "dwconv_bwd_weight")
+    span.done()
     return dw
 
 

@@ -339,8 +339,11 @@ int icap_embedding_bwd_f32(const long long* idx, const float* dy, int ldd, int P
  * gradient together with the pooled mean's gradient, global-average-pool backward. */
 int icap_chan_affine_f32(const float* x, const float* g, const float* a, float alpha, int B, int HW, int C, float* y,
                          void* stream);
-/* out[b][c] = scale * sum_p x[b,p,c] * y[b,p,c] (y NULL: sum of x): gradient of the squeeze-excite gate. */
-int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, void* stream);
+/* out[b][c] = scale * sum_p x[b,p,c] * y[b,p,c] (y NULL: sum of x): gradient of the squeeze-excite gate, and
+ * the pooled mean.  ws: icap_image_dot_ws_floats(B, HW, C) floats. */
+int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, float* ws,
+                       void* stream);
+long long icap_image_dot_ws_floats(int B, int HW, int C);
 
 /* Depthwise convolution gradients (weights [K*K][C], TF-"same" padding given as pad_t / pad_l). */
 int icap_dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, int C, int K, int S, int pad_t,

@@ -165,7 +165,7 @@ def test_full_model_training_step_matches_oracle():
             assert torch.equal(prm.detach(), before[name]), name          # no gradient: untouched by the optimizer
             continue
         err = (prm.grad.cpu() - want).abs().max().item()
-        if err > 3e-2 * want.abs().max().item() + 2e-5:
+        if err > 3e-2 * want.abs().max().item() + 1e-4:
             bad.append((name, err, want.abs().max().item()))
     assert not bad, bad[:10]
     moved = sum(int(not torch.equal(prm.detach(), before[n])) for n, prm in model.named_parameters())

@@ -83,7 +83,7 @@ def test_efficientnet_training_forward_backward_matches_oracle():
         # subtraction: _bn2.bias and friends have a true gradient of ~0 and hold rounding noise on both sides,
         # hence the absolute floor
         err = (got.cpu() - want).abs().max().item()
-        if err > 2e-2 * want.abs().max().item() + 2e-5:
+        if err > 2e-2 * want.abs().max().item() + 1e-4:
             bad.append((name, err, want.abs().max().item()))
     assert not bad, bad[:10]
     sd_after = model.state_dict()

@@ -57,7 +57,7 @@ struct SetTag { static constexpr int value = S; };
 // PF2: two K slices in flight in registers instead of one (needs an even number of K steps).  A
 // workgroup that is alone on its CU - few-tile problems such as the decoder GEMMs at 256 rows -
 // otherwise stalls every step for the part of the memory latency one step of MFMAs does not cover.
-template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC, bool PF2 = false>
+template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC, bool PF2 = false, bool AMAX = false>
 __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = 64 * WM * WN * KSPLIT;   // threads: one wave per (row block, column block, K split)
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
                 __syncthreads();
                 for (int row = erow; row < EP_R && erow < EP_RPI; row += EP_RPI) {
                     const int m = em0 + r0 + row;
-                    if constexpr (VEC && (BN4 & (BN4 - 1)) == 0) {
-                        if (p.amax_val) {
+                    if constexpr (AMAX && VEC && (BN4 & (BN4 - 1)) == 0) {
+                        {
                             // Row maximum over this tile's columns: the BN4 lanes that hold one row are contiguous
                             // in the wave, so a width-BN4 butterfly reduces them; first index wins ties.
                             float bv = -INFINITY;
@@ -430,7 +430,9 @@ static int persistent_grid(K kernel, int nblk, int& cached, int threads) {
     return cached & ~7;                // several tiles per workgroup: the stride must keep tile % 8 fixed
 }
 
-template <int BM, int BN, int WM, int WN, int KSPLIT, int KU = 1, bool VEC = true, bool PF2 = false>
+// AMAX: the epilogue also emits per-tile row maxima (its own kernel instantiation, so that profiles show the
+// vocabulary projection of greedy decoding under its own name).
+template <int BM, int BN, int WM, int WN, int KSPLIT, int KU = 1, bool VEC = true, bool PF2 = false, bool AMAX = false>
 static int launch_cfg(ConvParams& p, hipStream_t st) {
     if (PF2 && (((p.K + BK * KSPLIT * KU - 1) / (BK * KSPLIT * KU)) & 1)) {
         set_error("conv_igemm: this tile configuration needs an even number of K steps");
@@ -449,7 +451,7 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
 #define ICAP_LAUNCH(O_, G_)                                                                          \
     do {                                                                                             \
         static int cached = 0;                                                                       \
-        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC, PF2>;                               \
+        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC, PF2, AMAX>;                               \
         hipLaunchKernelGGL(kern, dim3((unsigned)persistent_grid(kern, p.nblk, cached, (int)block.x)), block, 0, st, p); \
     } while (0)
     if (one && p.gate) ICAP_LAUNCH(true, true);
@@ -644,8 +646,8 @@ int linear_argmax_f32(const float* x, const float* w, const float* scale, const 
     p.y = y;
     p.amax_val = part_val;
     p.amax_idx = part_idx;
-    if ((((K + BK - 1) / BK) & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, true>(p, st);
-    return launch_cfg<64, 64, 2, 2, 1, 2>(p, st);
+    if ((((K + BK - 1) / BK) & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, true, true>(p, st);
+    return launch_cfg<64, 64, 2, 2, 1, 2, true, false, true>(p, st);
 }
 
 int conv_igemm_tuned_cfg(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo) {

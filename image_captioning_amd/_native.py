@@ -100,6 +100,7 @@ SIGNATURES = {
     "icap_ln_train_fwd_f32": (_i, [_p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p]),
     "icap_ln_bwd_f32": (_i, [_p, _p, _p, _p, _p, _f, _i, _i, _p, _p]),
     "icap_lstm_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
+    "icap_gru_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "icap_att_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "icap_embedding_bwd_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "icap_chan_affine_f32": (_i, [_p, _p, _p, _f, _i, _i, _i, _p, _p]),

@@ -206,7 +206,7 @@ class VGGTrunk(nn.Sequential):
         return plan
 
     def forward(self, images: torch.Tensor) -> torch.Tensor:
-        require_eval(self, "VGG-16 trunk")
+        # no BatchNorm, no dropout in vgg16.features: train() and eval() compute the same thing
         plan = self._prep.get(self, self._build)
         x = ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)
         for st in plan:

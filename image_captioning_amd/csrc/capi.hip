@@ -72,6 +72,7 @@ int ln_train_fwd_f32(const float*, const float*, const float*, const float*, flo
                      hipStream_t);
 int ln_bwd_f32(const float*, const float*, const float*, const float*, const float*, float, int, int, float*, hipStream_t);
 int lstm_bwd_f32(const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, hipStream_t);
+int gru_bwd_f32(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
 int att_bwd_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, float*,
                 float*, float*, float*, float*, float*, hipStream_t);
 int embedding_bwd_f32(const long long*, const float*, int, int, int, int, float*, hipStream_t);
@@ -452,6 +453,11 @@ int icap_ln_bwd_f32(const float* dy, const float* xs, const float* gamma, const 
 int icap_lstm_bwd_f32(const float* gates, const float* c_in, const float* c_out, const float* dh, const float* dc, int B, int H,
                       float* dgates, float* dc_prev, void* stream) {
     return lstm_bwd_f32(gates, c_in, c_out, dh, dc, B, H, dgates, dc_prev, (hipStream_t)stream);
+}
+
+int icap_gru_bwd_f32(const float* gi, const float* gh, const float* h_in, const float* dh, int B, int H, float* dgi, float* dgh,
+                     float* dh_direct, void* stream) {
+    return gru_bwd_f32(gi, gh, h_in, dh, B, H, dgi, dgh, dh_direct, (hipStream_t)stream);
 }
 
 int icap_att_bwd_f32(const float* u, const float* w, const float* a_w, const float* alpha, const float* feat, const float* dctx,

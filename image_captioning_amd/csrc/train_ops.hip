@@ -479,6 +479,42 @@ int lstm_bwd_f32(const float* gates, const float* c_in, const float* c_out, cons
     return launch_status("lstm_bwd");
 }
 
+// ---------------------------------------------------------------- GRU cell gradient
+// Forward (gate order r, z, n; gi = W_ih x + b_ih, gh = W_hh h + b_hh, both [B][3H]):
+//   r = sig(gi_r + gh_r), z = sig(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h.
+// Given dh': dgi, dgh (pre-activation gradients of the two halves) and the direct path dh_direct = dh' * z.
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                      const float* __restrict__ h_in, const float* __restrict__ dh, int B, int H,
+                                                      float* __restrict__ dgi, float* __restrict__ dgh,
+                                                      float* __restrict__ dh_direct) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    const float* a = gi + (size_t)b * 3 * H;
+    const float* c = gh + (size_t)b * 3 * H;
+    const float r = sigmoidf_(a[j] + c[j]);
+    const float z = sigmoidf_(a[H + j] + c[H + j]);
+    const float ghn = c[2 * H + j];
+    const float n = tanhf(a[2 * H + j] + r * ghn);
+    const float d = dh[i];
+    const float dpn = d * (1.f - z) * (1.f - n * n);
+    const float dpr = dpn * ghn * r * (1.f - r);
+    const float dpz = d * (h_in[i] - n) * z * (1.f - z);
+    float* oa = dgi + (size_t)b * 3 * H;
+    float* oc = dgh + (size_t)b * 3 * H;
+    oa[j] = dpr; oc[j] = dpr;
+    oa[H + j] = dpz; oc[H + j] = dpz;
+    oa[2 * H + j] = dpn; oc[2 * H + j] = dpn * r;
+    dh_direct[i] = d * z;
+}
+
+int gru_bwd_f32(const float* gi, const float* gh, const float* h_in, const float* dh, int B, int H, float* dgi, float* dgh,
+                float* dh_direct, hipStream_t st) {
+    if (!gi || !gh || !h_in || !dh || !dgi || !dgh || !dh_direct || B <= 0 || H <= 0) { set_error("gru_bwd: bad arguments"); return ICAP_ERR_ARG; }
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, gi, gh, h_in, dh, B, H, dgi, dgh, dh_direct);
+    return launch_status("gru_bwd");
+}
+
 // ---------------------------------------------------------------- additive attention gradient
 // Forward (transformer_word_level_bahdnau.py:102-110): score[i][j] = a_w . tanh(u[j] + w[i]) + a_b,
 // alpha[i] = softmax_j(score[i]), context[i] = sum_j alpha[i][j] feat[j].

@@ -50,7 +50,13 @@ class EncoderCNN(nn.Module):
         return w.float().contiguous(), scale, bias
 
     def forward(self, images):
-        require_eval(self, "EncoderCNN")
+        if self.training:
+            from ._s2s_train import EncoderHeadTrain, resnet_trunk_train
+            vgg = self.cnn_type.startswith("vgg")
+            with torch.no_grad():                                       # seq2seqbasic.py:41
+                feats = self.cnn(images) if vgg else resnet_trunk_train(self.cnn, images)
+            feats = feats.reshape(images.size(0), -1).contiguous()
+            return EncoderHeadTrain.apply(feats, self.fc.weight, self.fc.bias, self.bn.weight, self.bn.bias, self.bn, vgg)
         feats = self.cnn(images)
         feats = feats.reshape(images.size(0), -1)
         w, scale, bias = self._prep.get(self, self._build)
@@ -99,7 +105,9 @@ class DecoderRNN(nn.Module):
     # -- teacher-forced forward ---------------------------------------------------
     def forward(self, features, captions):
         """features [B, embed], captions [B, T] -> logits [B, T, V]  (seq2seqbasic.py:59-66)."""
-        require_eval(self, "DecoderRNN")
+        if self.training:
+            from ._s2s_train import decoder_train
+            return decoder_train(self, features, captions)
         wd = self._weights()
         B, T = captions.shape
         H = self.hidden_size

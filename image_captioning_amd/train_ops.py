@@ -200,6 +200,17 @@ def lstm_bwd(gates, c_in, c_out, dh, dc):
     return dg, dcp
 
 
+def gru_bwd(gi, gh, h_in, dh):
+    """Returns (dgi [B, 3H], dgh [B, 3H], dh_direct [B, H])."""
+    B, H3 = gi.shape
+    H = H3 // 3
+    dgi = torch.empty(B, H3, device=gi.device); dgh = torch.empty(B, H3, device=gi.device)
+    dhd = torch.empty(B, H, device=gi.device)
+    N.check(N.load().icap_gru_bwd_f32(gi.data_ptr(), gh.data_ptr(), h_in.data_ptr(), dh.data_ptr(), B, H, dgi.data_ptr(), dgh.data_ptr(),
+                                      dhd.data_ptr(), _stream()), "gru_bwd")
+    return dgi, dgh, dhd
+
+
 def attention_bwd(u, w, a_w, alpha, feat, dctx, du, dfeat, accumulate):
     """Returns (dw [B, A], da_part [B, A], dab_part [B]); du / dfeat are written or accumulated in place."""
     B, A = u.shape

@@ -202,6 +202,39 @@ class AdamW:
                 "eps": self.eps, "weight_decay": self.weight_decay}
 
 
+class Adam(AdamW):
+    """torch.optim.Adam(params, lr) as selected by ``optimizer_type="adam"`` at seq2seqbasic.py:205-210: with its
+    default weight_decay = 0 the update is AdamW's without the decay term."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0.0)
+
+
+class SGD:
+    """torch.optim.SGD(params, lr) without momentum (``optimizer_type="sgd"``, seq2seqbasic.py:208): p -= lr * g over
+    the flat buffer, parameters without a gradient untouched."""
+
+    def __init__(self, params, lr=1e-3):
+        self.flat = params if isinstance(params, FlatParameters) else FlatParameters(params)
+        if self.flat.flat_p.device.type != "cuda":
+            raise N.IcapError("SGD: parameters must live on the HIP device (no CPU path)")
+        self.lr = float(lr)
+
+    @property
+    def params(self):
+        return self.flat.params
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        self.flat.zero_grad(set_to_none)
+
+    def step(self) -> None:
+        f = self.flat
+        lib = N.load()
+        for lo, hi in f.touched_runs():
+            N.check(lib.icap_axpby_f32(f.flat_g.data_ptr() + 4 * lo, -self.lr * float(f.grad_scale), 1.0, f.flat_p.data_ptr() + 4 * lo,
+                                       hi - lo, _stream()), "sgd")
+
+
 # ---------------------------------------------------------------------------- data-parallel gradient exchange
 class GradientReducer:
     """Sums the flat gradient buffer of ``FlatParameters`` (or of an ``AdamW``) across the ranks of a process
@@ -217,7 +250,7 @@ class GradientReducer:
     def __init__(self, flat, group=None, bucket_mb: float = 16.0, overlap: bool = True):
         import torch.distributed as dist
         self.dist = dist
-        optimizer = flat.flat if isinstance(flat, AdamW) else flat
+        optimizer = flat.flat if isinstance(flat, (AdamW, SGD)) else flat
         self.opt = optimizer
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1

@@ -320,6 +320,11 @@ int icap_ln_bwd_f32(const float* dy, const float* xs, const float* gamma, const 
 int icap_lstm_bwd_f32(const float* gates, const float* c_in, const float* c_out, const float* dh, const float* dc,
                       int B, int H, float* dgates, float* dc_prev, void* stream);
 
+/* Gradient of one nn.GRU cell step (seq2seqbasic.py:52,63): from dh' to the pre-activation gradients of the input
+ * half dgi and the recurrent half dgh ([B][3H], gate order r, z, n) and the direct path dh_direct = dh' * z. */
+int icap_gru_bwd_f32(const float* gi, const float* gh, const float* h_in, const float* dh, int B, int H, float* dgi,
+                     float* dgh, float* dh_direct, void* stream);
+
 /* Gradient of Attention.forward (transformer_word_level_bahdnau.py:102-110) for one decode step: from dctx
  * [B][E] to dw [B][A] (query projections), du [B][A] and dfeat [B][E] (key side, optionally accumulated over
  * steps), per-query partials da_part [B][A], dab_part [B] of the scoring vector's gradient, dscore [B][B]. */

@@ -33,8 +33,16 @@ def _bn(sd, p, x, eps):
 # --------------------------------------------------------------------------- ResNet-18 trunk (keys "0", "1", "4".."7")
 
 
-def resnet18_trunk(sd, x, p=""):
-    x = F.relu(_bn(sd, p + "1", F.conv2d(x, sd[p + "0.weight"], stride=2, padding=3), 1e-5))
+def resnet18_trunk(sd, x, p="", training=False, bufs=None):
+    """torchvision resnet18 children[:-1].  training=True: BatchNorm uses the batch statistics and updates the running
+    statistics in ``bufs`` (momentum 0.1) - what model.train() does to the reference's frozen backbone
+    (seq2seqbasic.py:41 only switches gradients off, not the BatchNorm mode)."""
+    def bn(name, t):
+        if not training:
+            return _bn(sd, name, t, 1e-5)
+        return F.batch_norm(t, bufs[name + ".running_mean"], bufs[name + ".running_var"], sd[name + ".weight"], sd[name + ".bias"],
+                            training=True, momentum=0.1, eps=1e-5)
+    x = F.relu(bn(p + "1", F.conv2d(x, sd[p + "0.weight"], stride=2, padding=3)))
     x = F.max_pool2d(x, 3, 2, 1)
     for li in (4, 5, 6, 7):
         for bi in (0, 1):
@@ -42,9 +50,9 @@ def resnet18_trunk(sd, x, p=""):
             stride = 2 if (li > 4 and bi == 0) else 1
             idn = x
             if q + "downsample.0.weight" in sd:
-                idn = _bn(sd, q + "downsample.1", F.conv2d(x, sd[q + "downsample.0.weight"], stride=stride), 1e-5)
-            h = F.relu(_bn(sd, q + "bn1", F.conv2d(x, sd[q + "conv1.weight"], stride=stride, padding=1), 1e-5))
-            h = _bn(sd, q + "bn2", F.conv2d(h, sd[q + "conv2.weight"], padding=1), 1e-5)
+                idn = bn(q + "downsample.1", F.conv2d(x, sd[q + "downsample.0.weight"], stride=stride))
+            h = F.relu(bn(q + "bn1", F.conv2d(x, sd[q + "conv1.weight"], stride=stride, padding=1)))
+            h = bn(q + "bn2", F.conv2d(h, sd[q + "conv2.weight"], padding=1))
             x = F.relu(h + idn)
     return F.adaptive_avg_pool2d(x, 1)
 

@@ -56,6 +56,30 @@ def main():
     np.savez_compressed(os.path.join(OUT, "bahdanau_train_small.npz"), **res)
     print("loss", float(loss), "->", OUT)
 
+    # ---- seq2seq decoders in train() mode: forward, CrossEntropyLoss(ignore_index=PAD) as at seq2seqbasic.py:204,219, backward
+    import seq2seqbasic as ref_s2s
+    from image_captioning_amd import seq2seqbasic as my_s2s
+    for kind in ("lstm", "gru"):
+        E, H, V, L, B, T = 32, 64, 97, 2, 5, 7
+        mine = my_s2s.DecoderRNN(E, H, V, num_layers=L, rnn_type=kind)
+        sd = seeded_state_dict(mine, seed=11)
+        ref = ref_s2s.DecoderRNN(E, H, V, num_layers=L, rnn_type=kind)
+        ref.load_state_dict(sd, strict=True)
+        ref.train()
+        feats = features(B, E, 601).requires_grad_(True)
+        caps = captions(B, T, V, 602)
+        caps[0, 4:] = 0
+        caps[3, 2:] = 0
+        out = ref(feats, caps)
+        loss = torch.nn.CrossEntropyLoss(ignore_index=0)(out.view(-1, V), caps.view(-1))
+        loss.backward()
+        res = {"dims": np.array([E, H, V, L, B, T]), "caps": caps.numpy(), "loss": float(loss), "logits": out.detach().numpy(),
+               "grad_feats": feats.grad.numpy()}
+        for k, p in ref.named_parameters():
+            res["grad." + k] = p.grad.numpy()
+        np.savez_compressed(os.path.join(OUT, f"seq2seq_{kind}_train_small.npz"), **res)
+        print("seq2seq", kind, "train loss", float(loss))
+
 
 if __name__ == "__main__":
     main()

@@ -98,3 +98,22 @@ def test_adamw_matches_torch(wd, lr):
             o.step()
     for a, b in zip(mine.parameters(), ref.parameters()):
         torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+def test_seq2seq_optimizer_choices_match_torch(kind):
+    """optimizer_type "adam" / "sgd" of seq2seqbasic.py:205-210."""
+    from image_captioning_amd.training import SGD, Adam
+    ref = _mlp()
+    mine = _mlp().to(dev())
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-3) if kind == "adam" else torch.optim.SGD(ref.parameters(), lr=1e-2)
+    opt = Adam(mine.parameters(), lr=1e-3) if kind == "adam" else SGD(mine.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(6)
+    for _ in range(4):
+        x, y = torch.randn(16, 33, generator=g), torch.randn(16, 10, generator=g)
+        for model, o, xx, yy in ((ref, opt_ref, x, y), (mine, opt, x.to(dev()), y.to(dev()))):
+            o.zero_grad()
+            ((model(xx) - yy) ** 2).mean().backward()
+            o.step()
+    for a, b in zip(mine.parameters(), ref.parameters()):
+        torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=2e-5, atol=5e-7)

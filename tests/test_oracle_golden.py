@@ -147,3 +147,24 @@ def test_bahdanau_training_step_oracle_matches_reference():
         torch.testing.assert_close(got, want.view_as(got), rtol=2e-3, atol=2e-6, msg=lambda m: f"{name}: {m}")   # a bias in front of a train-mode BatchNorm has gradient 0 up to rounding
     torch.testing.assert_close(dec_bn["running_mean"], torch.from_numpy(g["after.decoder.fc.1.running_mean"]), rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(enc_bn["running_var"], torch.from_numpy(g["after.encoder.fc.3.running_var"]), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["lstm", "gru"])
+def test_seq2seq_training_oracle_matches_reference(kind):
+    """Oracle decoder forward + CrossEntropyLoss(ignore_index) + autograd against the reference's DecoderRNN in train()."""
+    from image_captioning_amd import seq2seqbasic as my_s2s
+    from image_captioning_amd.synthetic import seeded_state_dict
+    g = H.load(f"seq2seq_{kind}_train_small")
+    E, HD, V, L, B, T = [int(v) for v in g["dims"]]
+    sd = {k: v.clone().requires_grad_(True) for k, v in seeded_state_dict(my_s2s.DecoderRNN(E, HD, V, num_layers=L, rnn_type=kind), seed=11).items()}
+    feats = torch.randn(B, E, generator=torch.Generator().manual_seed(601)).requires_grad_(True)
+    caps = torch.from_numpy(g["caps"])
+    out = R.seq2seq_decoder_forward(sd, feats, caps)
+    loss = R.seq2seq_loss(out, caps, 0)
+    loss.backward()
+    torch.testing.assert_close(out.detach(), torch.from_numpy(g["logits"]), rtol=1e-4, atol=1e-5)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    torch.testing.assert_close(feats.grad, torch.from_numpy(g["grad_feats"]), rtol=1e-3, atol=1e-7)
+    for k in g:
+        if k.startswith("grad."):
+            torch.testing.assert_close(sd[k[5:]].grad, torch.from_numpy(g[k]), rtol=2e-3, atol=1e-6, msg=lambda m: f"{k}: {m}")

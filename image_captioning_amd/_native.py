@@ -102,6 +102,7 @@ SIGNATURES = {
     "icap_lstm_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "icap_gru_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "icap_att_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "icap_mha_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "icap_embedding_bwd_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "icap_chan_affine_f32": (_i, [_p, _p, _p, _f, _i, _i, _i, _p, _p]),
     "icap_image_dot_f32": (_i, [_p, _p, _i, _i, _i, _f, _p, _p, _p]),

@@ -176,15 +176,18 @@ class ImageCaptioningModelBase(nn.Module):
         self.caption_embedding = nn.Embedding(vocab_size, embed_dim)
         self._prep = PreparedCache()
 
+    dropout_masks = None   # tests: factor tensors instead of generated dropout masks (see _tfm_train.model_train_forward)
+
     def forward(self, images, captions):
         """images [B,3,H,W], captions [B,T] int64 -> logits [B,T,V]  (transformer_word_level.py:92-112)."""
-        require_eval(self, "ImageCaptioningModel")
         img_embed = self.cnn_model(images)                                  # [B, E]
         return self.forward_features(img_embed, captions)
 
     def forward_features(self, img_embed, captions):
         """Same as forward but from the CNN output [B, E]."""
-        require_eval(self, "ImageCaptioningModel")
+        if self.training:
+            from ._tfm_train import model_train_forward
+            return model_train_forward(self, img_embed, captions, self.dropout_masks)
         B, T = captions.shape
         E = img_embed.shape[-1]
         enc = self.encoder(img_embed.view(1, B, E))                         # [B, 1, E], coupled across the batch

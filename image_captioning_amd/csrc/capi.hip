@@ -75,6 +75,7 @@ int lstm_bwd_f32(const float*, const float*, const float*, const float*, const f
 int gru_bwd_f32(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
 int att_bwd_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, float*,
                 float*, float*, float*, float*, float*, hipStream_t);
+int mha_bwd_f32(const float*, const float*, const float*, const float*, int, int, int, int, float*, float*, float*, float*, hipStream_t);
 int embedding_bwd_f32(const long long*, const float*, int, int, int, int, float*, hipStream_t);
 
 int chan_affine_f32(const float*, const float*, const float*, float, int, int, int, float*, hipStream_t);
@@ -464,6 +465,11 @@ int icap_att_bwd_f32(const float* u, const float* w, const float* a_w, const flo
                      int B, int A, int E, int accumulate, float* dscore, float* dw, float* da_part, float* dab_part, float* du,
                      float* dfeat, void* stream) {
     return att_bwd_f32(u, w, a_w, alpha, feat, dctx, B, A, E, accumulate, dscore, dw, da_part, dab_part, du, dfeat, (hipStream_t)stream);
+}
+
+int icap_mha_bwd_f32(const float* q, const float* k, const float* v, const float* dO, int R, int Bk, int E, int heads, float* dq,
+                     float* dk, float* dv, float* ws, void* stream) {
+    return mha_bwd_f32(q, k, v, dO, R, Bk, E, heads, dq, dk, dv, ws, (hipStream_t)stream);
 }
 
 int icap_embedding_bwd_f32(const long long* idx, const float* dy, int ldd, int P, int E, int V, float* dtable, void* stream) {

@@ -611,6 +611,119 @@ int att_bwd_f32(const float* u, const float* w, const float* a_w, const float* a
     return launch_status("att_bwd");
 }
 
+// ---------------------------------------------------------------- multi-head attention gradient
+// Forward per head h (width D = E / heads): S = scale * Q_h K_h^T  [R x Bk], P = softmax_rows(S), O_h = P V_h.
+// q, dO: [R][E]; k, v: [Bk][E].  Query side, one wave per (query r, head h): recompute P, then
+//   dP_j = dO_r . v_j,  dS_j = P_j (dP_j - sum_j' P_j' dP_j'),  dQ_r = scale * sum_j dS_j k_j;
+// P and dS ([R][heads][Bk]) are kept for the key side.
+constexpr int MHA_MAX_KEYS = 1024;
+constexpr int MHA_MAXD = 4;   // head width <= 256
+
+__global__ __launch_bounds__(64) void mha_bwd_query_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const float* __restrict__ dO, int Bk,
+                                                           int E, int heads, float scale, float* __restrict__ dq,
+                                                           float* __restrict__ P, float* __restrict__ dS) {
+    __shared__ float sc[MHA_MAX_KEYS];
+    __shared__ float dp[MHA_MAX_KEYS];
+    const int r = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int D = E / heads;
+    const size_t qo = (size_t)r * E + (size_t)h * D;
+    float qr[MHA_MAXD], gr[MHA_MAXD], acc[MHA_MAXD];
+#pragma unroll
+    for (int i = 0; i < MHA_MAXD; ++i) {
+        const int d = lane + 64 * i;
+        qr[i] = d < D ? q[qo + d] : 0.f;
+        gr[i] = d < D ? dO[qo + d] : 0.f;
+        acc[i] = 0.f;
+    }
+    float m = -INFINITY;
+    for (int j = 0; j < Bk; ++j) {
+        const size_t ko = (size_t)j * E + (size_t)h * D;
+        float s = 0.f, g = 0.f;
+#pragma unroll
+        for (int i = 0; i < MHA_MAXD; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) { s = fmaf(qr[i], k[ko + d], s); g = fmaf(gr[i], v[ko + d], g); }
+        }
+        s = wave_sum(s) * scale;
+        g = wave_sum(g);
+        if (lane == 0) { sc[j] = s; dp[j] = g; }
+        m = fmaxf(m, s);
+    }
+    __syncthreads();
+    float l = 0.f;
+    for (int j = lane; j < Bk; j += 64) l += expf(sc[j] - m);
+    l = wave_sum(l);
+    const float inv = 1.0f / l;
+    float delta = 0.f;
+    for (int j = lane; j < Bk; j += 64) {
+        const float pj = expf(sc[j] - m) * inv;
+        sc[j] = pj;
+        delta += pj * dp[j];
+    }
+    delta = wave_sum(delta);
+    __syncthreads();
+    const size_t po = ((size_t)r * heads + h) * Bk;
+    for (int j = lane; j < Bk; j += 64) {
+        const float ds = sc[j] * (dp[j] - delta);
+        P[po + j] = sc[j];
+        dS[po + j] = ds;
+        dp[j] = ds;
+    }
+    __syncthreads();
+    for (int j = 0; j < Bk; ++j) {
+        const size_t ko = (size_t)j * E + (size_t)h * D;
+        const float ds = dp[j];
+#pragma unroll
+        for (int i = 0; i < MHA_MAXD; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) acc[i] = fmaf(ds, k[ko + d], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MHA_MAXD; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) dq[qo + d] = acc[i] * scale;
+    }
+}
+
+// Key side, one workgroup per (key j, head h), thread = channel of the head:
+//   dK_j = scale * sum_r dS[r][h][j] q_r,   dV_j = sum_r P[r][h][j] dO_r   (r in order: deterministic).
+__global__ __launch_bounds__(256) void mha_bwd_key_kernel(const float* __restrict__ q, const float* __restrict__ dO,
+                                                          const float* __restrict__ P, const float* __restrict__ dS, int R, int Bk,
+                                                          int E, int heads, float scale, float* __restrict__ dk,
+                                                          float* __restrict__ dv) {
+    const int j = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    const int D = E / heads;
+    if (d >= D) return;
+    float ak = 0.f, av = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const size_t po = ((size_t)r * heads + h) * Bk + j;
+        const size_t qo = (size_t)r * E + (size_t)h * D + d;
+        ak = fmaf(dS[po], q[qo], ak);
+        av = fmaf(P[po], dO[qo], av);
+    }
+    const size_t ko = (size_t)j * E + (size_t)h * D + d;
+    dk[ko] = ak * scale;
+    dv[ko] = av;
+}
+
+int mha_bwd_f32(const float* q, const float* k, const float* v, const float* dO, int R, int Bk, int E, int heads, float* dq,
+                float* dk, float* dv, float* ws, hipStream_t st) {
+    if (!q || !k || !v || !dO || !dq || !dk || !dv || !ws || R <= 0 || Bk <= 0 || E <= 0 || heads <= 0 || E % heads) {
+        set_error("mha_bwd: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    const int D = E / heads;
+    if (Bk > MHA_MAX_KEYS || D > 64 * MHA_MAXD) { set_error("mha_bwd: %d keys / head width %d exceed %d / %d", Bk, D, MHA_MAX_KEYS, 64 * MHA_MAXD); return ICAP_ERR_LIMIT; }
+    const float scale = 1.0f / sqrtf((float)D);
+    float* P = ws;
+    float* dS = ws + (size_t)R * heads * Bk;
+    hipLaunchKernelGGL(mha_bwd_query_kernel, dim3(R, heads), dim3(64), 0, st, q, k, v, dO, Bk, E, heads, scale, dq, P, dS);
+    hipLaunchKernelGGL(mha_bwd_key_kernel, dim3(Bk, heads), dim3(256), 0, st, q, dO, P, dS, R, Bk, E, heads, scale, dk, dv);
+    return launch_status("mha_bwd");
+}
+
 // ---------------------------------------------------------------- embedding gradient
 // dtable[idx[p]][:] += dy[p][:] for p in order.  Workgroup g owns the table rows with row % gridDim.x == g, so
 // every row is updated by one workgroup in position order: deterministic without atomics.  dtable must be

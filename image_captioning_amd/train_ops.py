@@ -224,6 +224,18 @@ def attention_bwd(u, w, a_w, alpha, feat, dctx, du, dfeat, accumulate):
     return dw, da_part, dab_part
 
 
+def mha_bwd(q, k, v, dO, heads):
+    """Gradient of softmax(q k^T / sqrt(d)) v per head: q, dO [R, E]; k, v [Bk, E] -> (dq, dk, dv)."""
+    R, E = q.shape
+    Bk = k.shape[0]
+    dev = q.device
+    dq = torch.empty(R, E, device=dev); dk = torch.empty(Bk, E, device=dev); dv = torch.empty(Bk, E, device=dev)
+    ws = torch.empty(2 * R * heads * Bk, device=dev)
+    N.check(N.load().icap_mha_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), dO.data_ptr(), R, Bk, E, heads, dq.data_ptr(), dk.data_ptr(),
+                                      dv.data_ptr(), ws.data_ptr(), _stream()), "mha_bwd")
+    return dq, dk, dv
+
+
 def embedding_bwd(idx, dy, V):
     """dtable [V, E] = scatter-add of dy rows by idx (deterministic)."""
     P, E = dy.shape

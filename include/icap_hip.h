@@ -332,6 +332,12 @@ int icap_att_bwd_f32(const float* u, const float* w, const float* a_w, const flo
                      const float* dctx, int B, int A, int E, int accumulate, float* dscore, float* dw, float* da_part,
                      float* dab_part, float* du, float* dfeat, void* stream);
 
+/* Gradient of the attention core of nn.MultiheadAttention (softmax(QK^T/sqrt(d))V per head, no mask, no attention
+ * dropout) as the word / char transformer uses it: R query rows against Bk key rows (the images of the batch;
+ * transformer_word_level.py:45,73-74).  q, dO, dq [R][E]; k, v, dk, dv [Bk][E]; ws: 2*R*heads*Bk floats. */
+int icap_mha_bwd_f32(const float* q, const float* k, const float* v, const float* dO, int R, int Bk, int E, int heads,
+                     float* dq, float* dk, float* dv, float* ws, void* stream);
+
 /* nn.Embedding gradient: dtable[idx[p]] += dy[p], positions in order (deterministic); dtable pre-zeroed. */
 int icap_embedding_bwd_f32(const long long* idx, const float* dy, int ldd, int P, int E, int V, float* dtable,
                            void* stream);

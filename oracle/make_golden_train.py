@@ -80,6 +80,40 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"seq2seq_{kind}_train_small.npz"), **res)
         print("seq2seq", kind, "train loss", float(loss))
 
+    # ---- word / char transformer in train() mode with dropout 0: forward, data.compute_loss, backward
+    import transformer_word_level as ref_twl
+    import transformercharmiguel as ref_chr
+    import datachar as ref_dc
+    from image_captioning_amd import transformer_word_level as my_twl
+    from image_captioning_amd import transformercharmiguel as my_chr
+    for name, ref_mod, my_mod, (E, FF, eh, dh, V), pad in (("word", ref_twl, my_twl, (64, 128, 4, 4, 97), 0),
+                                                            ("char", ref_chr, my_chr, (64, 96, 2, 4, 81), 2)):
+        if name == "word":
+            ref_mod.vocab_size = V
+            my_mod.vocab_size = V
+        else:
+            assert ref_dc.NUM_CHAR == V
+        B, T = 5, 6
+        mine = my_mod.ImageCaptioningModel(FeaturePassThrough(), my_mod.TransformerEncoderBlock(E, FF, eh, dropout=0.0),
+                                           my_mod.TransformerDecoderBlock(E, FF, dh, dropout=0.0), embed_dim=E)
+        sd = seeded_state_dict(mine, seed=41)
+        ref = ref_mod.ImageCaptioningModel(FeaturePassThrough(), ref_mod.TransformerEncoderBlock(E, FF, eh, dropout=0.0),
+                                           ref_mod.TransformerDecoderBlock(E, FF, dh, dropout=0.0), embed_dim=E)
+        ref.load_state_dict(sd, strict=True)
+        ref.train()
+        feats = features(B, E, 701).requires_grad_(True)
+        caps = captions(B, T, V, 702, start=2 if name == "word" else 0)
+        caps[1, 4:] = pad
+        pred = ref(feats, caps)
+        loss = ref_data.compute_loss(pred[:, :-1], caps[:, 1:], pad)
+        loss.backward()
+        res = {"dims": np.array([E, FF, eh, dh, V, B, T, pad]), "caps": caps.numpy(), "loss": float(loss), "logits": pred.detach().numpy(),
+               "grad_feats": feats.grad.numpy()}
+        for k, p in ref.named_parameters():
+            res["grad." + k] = p.grad.numpy() if p.grad is not None else np.zeros(0, dtype=np.float32)
+        np.savez_compressed(os.path.join(OUT, f"{name}_tfm_train_small.npz"), **res)
+        print(name, "transformer train loss", float(loss))
+
 
 if __name__ == "__main__":
     main()

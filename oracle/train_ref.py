@@ -64,3 +64,32 @@ def bah_train_forward(sd, img_features, captions, enc_bn, dec_bn, masks=None):
     """ImageCaptioningModel.forward (lines 156-166) from post-CNN features, train mode."""
     enc = bah_encoder_train(sd, img_features, enc_bn, masks)
     return bah_decoder_train(sd, captions, enc, dec_bn, masks)
+
+
+# ---------------------------------------------------------------------------- word / char transformer, train mode
+def tfm_train_forward(sd, img_embed, captions, enc_heads, dec_heads, masks=None):
+    """ImageCaptioningModel.forward after the CNN (transformer_word_level.py:97-112, transformercharmiguel.py:98-113)
+    in train mode: the eval computation of oracle.torch_ref plus the five dropouts of lines 37, 40, 42 (encoder) and
+    67, 69, 71 (decoder).  masks: {"enc_att" [B, E], "enc_fc1" [B, FF], "enc_fc2" [B, E], "dec_att" [T, B, E],
+    "dec_fc1" [T, B, FF], "dec_fc2" [T, B, E]} factor tensors; a missing key means no dropping.
+    Pinned by tests/golden/{word,char}_tfm_train_small.npz (reference classes, dropout 0)."""
+    from oracle.torch_ref import _lin, _ln, mha
+    m = masks or {}
+    B = img_embed.shape[0]
+    # encoder: after the permute the B images are the attention sequence (L = B, N = 1)
+    x = img_embed.unsqueeze(0).permute(1, 0, 2)
+    a = mha(sd, "encoder.attention", x, x, x, enc_heads)
+    x = _ln(sd, "encoder.layer_norm1", x + _drop(a, None if m.get("enc_att") is None else m["enc_att"].view(B, 1, -1)))
+    h = _drop(torch.relu(_lin(sd, "encoder.fc.0", x)), None if m.get("enc_fc1") is None else m["enc_fc1"].view(B, 1, -1))
+    f = _drop(_lin(sd, "encoder.fc.3", h), None if m.get("enc_fc2") is None else m["enc_fc2"].view(B, 1, -1))
+    enc = _ln(sd, "encoder.layer_norm2", x + f)                                         # [B, 1, E]
+    # decoder
+    y = sd["caption_embedding.weight"][captions].permute(1, 0, 2)                       # [T, B, E]
+    T = y.shape[0]
+    kv = enc.repeat(T, B, 1)
+    ca = mha(sd, "decoder.cross_attention", y, kv, kv, dec_heads)
+    y = _ln(sd, "decoder.layer_norm2", y + _drop(ca, m.get("dec_att")))
+    h = _drop(torch.relu(_lin(sd, "decoder.fc.0", y)), m.get("dec_fc1"))
+    f = _drop(_lin(sd, "decoder.fc.3", h), m.get("dec_fc2"))
+    y = _ln(sd, "decoder.layer_norm3", y + f)
+    return _lin(sd, "decoder.output_fc", y).permute(1, 0, 2)

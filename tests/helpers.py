@@ -40,15 +40,15 @@ def rnn_decoder(kind, dims):
     return m.eval()
 
 
-def tfm_model(which, dims, cnn=None):
+def tfm_model(which, dims, cnn=None, seed=21, dropout=0.3):
     E, FF, eh, dh, V = [int(v) for v in dims[:5]]
     mod = twl if which == "word" else chr_
     if which == "word":
         twl.vocab_size = V
-    enc = mod.TransformerEncoderBlock(E, FF, eh)
-    dec = mod.TransformerDecoderBlock(E, FF, dh)
+    enc = mod.TransformerEncoderBlock(E, FF, eh, dropout=dropout)
+    dec = mod.TransformerDecoderBlock(E, FF, dh, dropout=dropout)
     m = mod.ImageCaptioningModel(cnn if cnn is not None else FeaturePassThrough(), enc, dec, embed_dim=E)
-    sd = seeded_state_dict(m, seed=21)
+    sd = seeded_state_dict(m, seed=seed)
     m.load_state_dict(sd)
     return m.eval()
 

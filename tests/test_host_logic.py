@@ -59,14 +59,14 @@ def test_word_model_needs_vocab_size_like_the_reference():
     assert twl.TransformerDecoderBlock(64, 128, 4).output_fc.out_features == 33
 
 
-def test_no_cpu_fallback_and_no_training_forward():
+def test_no_cpu_fallback_in_eval_or_train_mode():
     dec = H.rnn_decoder("lstm", [32, 64, 97, 2])
     with pytest.raises(ops.IcapError):
         dec.sample(torch.zeros(32))                       # CPU tensor: the HIP path refuses, nothing falls back
     with pytest.raises(ops.IcapError):
         dec.train()(torch.zeros(2, 32), torch.zeros(2, 5, dtype=torch.long))   # the training forward has no CPU path either
     tfm = H.tfm_model("word", [64, 128, 4, 4, 97])
-    with pytest.raises(NotImplementedError):             # train mode of the word / char transformer is not built
+    with pytest.raises(ops.IcapError):
         tfm.train().forward_features(torch.zeros(2, 64), torch.zeros(2, 5, dtype=torch.long))
     with pytest.raises(ops.IcapError):
         ops.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))

@@ -168,3 +168,26 @@ def test_seq2seq_training_oracle_matches_reference(kind):
     for k in g:
         if k.startswith("grad."):
             torch.testing.assert_close(sd[k[5:]].grad, torch.from_numpy(g[k]), rtol=2e-3, atol=1e-6, msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("name", ["word", "char"])
+def test_transformer_training_oracle_matches_reference(name):
+    """oracle.train_ref.tfm_train_forward + compute_loss + autograd against the reference's classes in train() (dropout 0)."""
+    from oracle import train_ref as TR
+    g = H.load(f"{name}_tfm_train_small")
+    E, FF, eh, dh, V, B, T, pad = [int(v) for v in g["dims"]]
+    model = H.tfm_model(name, [E, FF, eh, dh, V], seed=41)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    feats = torch.randn(B, E, generator=torch.Generator().manual_seed(701)).requires_grad_(True)
+    caps = torch.from_numpy(g["caps"])
+    pred = TR.tfm_train_forward(sd, feats, caps, eh, dh)
+    loss = R.compute_loss(pred[:, :-1], caps[:, 1:], pad)
+    loss.backward()
+    torch.testing.assert_close(pred.detach(), torch.from_numpy(g["logits"]), rtol=1e-4, atol=1e-5)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    torch.testing.assert_close(feats.grad, torch.from_numpy(g["grad_feats"]), rtol=2e-3, atol=1e-7)
+    for k in g:
+        if k.startswith("grad.") and g[k].size:
+            torch.testing.assert_close(sd[k[5:]].grad, torch.from_numpy(g[k]), rtol=2e-3, atol=1e-6, msg=lambda m: f"{k}: {m}")
+        elif k.startswith("grad."):
+            assert sd[k[5:]].grad is None, k                 # the decoder's unused attention / layer_norm1

@@ -73,7 +73,14 @@ def gemm_work(sig):
     return 2.0 * a * b * c, 4.0 * (a * b + b * c + a * c)
 
 
-WORK = {"conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work,
+def expand_dw_work(sig):
+    """(B, H, W, Cin, Cexp, ks, stride, Ho, Wo): the expand GEMM + the depthwise taps; input read once, output written once."""
+    B, H, W, Cin, Cexp, ks, stride, Ho, Wo = sig
+    return (2.0 * B * H * W * Cin * Cexp + 2.0 * B * Ho * Wo * Cexp * ks * ks,
+            4.0 * (B * H * W * Cin + B * Ho * Wo * Cexp + Cexp * (Cin + ks * ks)))
+
+
+WORK = {"conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work, "expand_dwconv2d": expand_dw_work,
         # training-step launches: (flops, algorithmic bytes)
         "gemm_nn": gemm_work, "gemm_tn": gemm_work,
         "col_reduce": lambda s: (2.0 * s[1] * s[2], 4.0 * s[1] * s[2] * (2 if s[0] >= 2 else 1)),
@@ -196,8 +203,8 @@ def main():
         else:
             roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
         roof["kernel"] = f"{dom['name']}{list(dom['sig'])}"
+        roof["traffic"] = pmc_traffic(roof["kernel"])
         roof["avg_launch_ms"] = dom_ms
         if train:
             workload = ("transformer_word_level_bahdnau: teacher-forced training step (EfficientNet-B0 train mode + encoder block + "
@@ -222,6 +229,17 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed counter passes (FETCH_SIZE / WRITE_SIZE cannot be read from
+    inside this process: they come from separate `rocprofv3 --pmc` runs of this same command), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def breakdown(torch, ops, step, B):

@@ -322,11 +322,18 @@ class EfficientNetB0(nn.Module):
         for d in p["blocks"]:
             inp = x
             h = x
-            if d["expand"] is not None:
-                h = ops.conv2d(h, d["expand"][0], *d["expand"][1], act=ops.ACT_SWISH)
             lo, hi = same_pad(d["k"], d["stride"])
-            h, part = ops.dwconv2d(h, d["dw_w"], *d["dw_sb"], ks=d["k"], stride=d["stride"], pad=(lo, hi, lo, hi),
-                                   act=ops.ACT_SWISH, want_partial=True)
+            pad = (lo, hi, lo, hi)
+            if d["expand"] is not None and ops.expand_dwconv_supported(h.shape[1], h.shape[2], h.shape[3], d["dw_w"].shape[1],
+                                                                       d["k"], d["stride"], pad):
+                # early blocks: the 6x expanded activations stay on chip between the 1x1 and the depthwise convolution
+                h, part = ops.expand_dwconv2d(h, d["expand"][0], *d["expand"][1], d["dw_w"], *d["dw_sb"], ks=d["k"],
+                                              stride=d["stride"], pad=pad, want_partial=True)
+            else:
+                if d["expand"] is not None:
+                    h = ops.conv2d(h, d["expand"][0], *d["expand"][1], act=ops.ACT_SWISH)
+                h, part = ops.dwconv2d(h, d["dw_w"], *d["dw_sb"], ks=d["k"], stride=d["stride"], pad=pad,
+                                       act=ops.ACT_SWISH, want_partial=True)
             gate = ops.se_gate(part, h.shape[1] * h.shape[2], *d["se"])
             x = ops.conv2d(h, d["proj"][0], *d["proj"][1], residual=inp if d["skip"] else None, gate=gate)
         x = ops.conv2d(x, p["head_w"], *p["head_sb"], act=ops.ACT_SWISH)

@@ -31,6 +31,9 @@ int nchw_to_nhwc_pad_f32(const float*, float*, int, int, int, int, int, hipStrea
 int dwconv2d_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
                  int, int, int, int, int, hipStream_t);
 int dwconv_chunks(int, int, int, int, int);
+int expand_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                      float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int expand_dwconv_chunks(int, int, int, int, int, int);
 int se_gate_f32(const float*, int, float, const float*, const float*, const float*, const float*, float*, int, int, int,
                 hipStream_t);
 int maxpool2d_f32(const float*, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -146,6 +149,17 @@ int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const 
 }
 
 int icap_dwconv_chunks(int Ho, int Wo, int C, int KS, int stride) { return dwconv_chunks(Ho, Wo, C, KS, stride); }
+
+int icap_expand_dwconv_f32(const float* x, const float* w_exp, const float* exp_scale, const float* exp_bias, const float* w_dw,
+                           const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int H, int W, int Cin,
+                           int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+    return expand_dwconv_f32(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, y, partial, B, H, W, Cin, Cexp, KS, stride,
+                             pad_t, pad_l, Ho, Wo, (hipStream_t)stream);
+}
+
+int icap_expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int stride) {
+    return expand_dwconv_chunks(Ho, Wo, Cin, Cexp, KS, stride);
+}
 
 int icap_se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr, const float* br, const float* we,
                      const float* be, float* gate, int B, int C, int S, void* stream) {

@@ -43,7 +43,7 @@ struct ConvParams {
     float* y;
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act;
     int M, K, ldy;
-    int tiles_n, nblk, vec_ok;
+    int tiles_n, tiles_m, m_fast, nblk, vec_ok;
     float* amax_val;        // optional [M][tiles_n]: per-tile row maxima of the outputs (arg-max partials)
     int* amax_idx;          // their column indices
 };
@@ -54,10 +54,18 @@ constexpr int EP_ROWS = 64;  // output rows per epilogue pass
 template <int S>
 struct SetTag { static constexpr int value = S; };
 
-// PF2: two K slices in flight in registers instead of one (needs an even number of K steps).  A
+template <int S, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (S < N) {
+        f(SetTag<S>{});
+        static_for<S + 1, N>(f);
+    }
+}
+
+// PF: K slices in flight in registers (the number of K steps must be a multiple of it).  A
 // workgroup that is alone on its CU - few-tile problems such as the decoder GEMMs at 256 rows -
 // otherwise stalls every step for the part of the memory latency one step of MFMAs does not cover.
-template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC, bool PF2 = false, bool AMAX = false>
+template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC, int PF = 1, bool AMAX = false>
 __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = 64 * WM * WN * KSPLIT;   // threads: one wave per (row block, column block, K split)
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -105,8 +113,10 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
     auto setup_tile = [&](int tl) {
         const int xcd = tl & 7, q = p.nblk >> 3, r = p.nblk & 7;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tl >> 3);
-        const int tile_n = logical % p.tiles_n;
-        const int tile_m = logical / p.tiles_n;
+        // tiles that share an XCD's L2 should re-read the LARGER operand: n fastest when the activations dominate
+        // (convolutions), m fastest when the weights do (a vocabulary projection at a few hundred rows)
+        const int tile_n = p.m_fast ? logical / p.tiles_m : logical % p.tiles_n;
+        const int tile_m = p.m_fast ? logical % p.tiles_m : logical / p.tiles_n;
         m0 = tile_m * BM;
         n0 = tile_n * BN;
 #pragma unroll
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
     // consumes a loaded value before lds_store(), so the loads of the next slice - or of the next
     // tile's first slice - stay in flight behind the MFMAs and the epilogue instead of being waited
     // for where they are issued.
-    constexpr int NSET = PF2 ? 2 : 1;
+    constexpr int NSET = PF;
     float4 ra[NSET][RA], rb[NSET][RB], rg[NSET][GATE ? RA : 1];
     unsigned okmask_s[NSET];   // bit i: ra[i] valid, bit 16+i: rb[i] valid
 
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
     if (tl >= p.nblk) return;
     setup_tile(tl);
     gload(0, SetTag<0>{});
-    if constexpr (PF2) gload(1, SetTag<1>{});
+    static_for<1, PF>([&](auto st) { gload(decltype(st)::value, st); });
 
     float* ep = smem;  // [KSPLIT][EP_R][EP_LD]; aliases the staging buffers, used only between K loops
     constexpr int BN4 = BN / 4;
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
     const int en4 = tid % BN4, erow = tid / BN4;
 
     while (true) {
-        // registers hold K slice 0 (and 1 with PF2) of tile tl, staging coordinates describe tile tl
+        // registers hold K slices 0..PF-1 of tile tl, staging coordinates describe tile tl
         lds_store(0, SetTag<0>{});
         __syncthreads();
         const int em0 = m0, en0 = n0;
@@ -257,41 +267,37 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
             }
         };
 
-        if constexpr (PF2) {
-            // Step t fetches slice t+2 into the register set slice t came from, multiplies slice t, then
-            // moves slice t+1 (fetched a whole step earlier) into the other LDS buffer.  The steady-state
-            // loop body is branch-free so that the compiler's wait counts let the newest fetch stay in
-            // flight across the LDS store; the last two steps fetch the next tile's slices 0 and 1
-            // (nk is even, so they land in sets 0 and 1 again).
-            for (int t = 0; t + 2 < nk; t += 2) {
-                // the scheduling fences keep the compiler from hoisting the store's use of fetched
-                // registers (and with it a full wait) above the MFMAs
-                gload(t + 2, SetTag<0>{});
-                __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PF > 1) {
+            // Step t fetches slice t+PF into the register set slice t came from, multiplies slice t, then
+            // moves slice t+1 (fetched PF-1 steps earlier) into the other LDS buffer.  The steady-state
+            // loop body is branch-free so that the compiler's wait counts let the newer fetches stay in
+            // flight across the LDS store; the last PF steps fetch the next tile's slices 0..PF-1
+            // (nk is a multiple of PF, so they land in sets 0..PF-1 again).
+            for (int t = 0; t + PF < nk; t += PF) {
+                static_for<0, PF>([&](auto st) {
+                    constexpr int S = decltype(st)::value;
+                    // the scheduling fences keep the compiler from hoisting the store's use of fetched
+                    // registers (and with it a full wait) above the MFMAs
+                    gload(t + S + PF, SetTag<S>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute();
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds_store(cur ^ 1, SetTag<(S + 1) % PF>{});
+                    __syncthreads();
+                    cur ^= 1;
+                });
+            }
+            static_for<0, PF>([&](auto st) {
+                constexpr int S = decltype(st)::value;
+                if (has_next) {
+                    if constexpr (S == 0) setup_tile(next);
+                    gload(S, SetTag<S>{});
+                }
                 compute();
-                __builtin_amdgcn_sched_barrier(0);
-                lds_store(cur ^ 1, SetTag<1>{});
+                if constexpr (S + 1 < PF) lds_store(cur ^ 1, SetTag<S + 1>{});
                 __syncthreads();
                 cur ^= 1;
-                gload(t + 3, SetTag<1>{});
-                __builtin_amdgcn_sched_barrier(0);
-                compute();
-                __builtin_amdgcn_sched_barrier(0);
-                lds_store(cur ^ 1, SetTag<0>{});
-                __syncthreads();
-                cur ^= 1;
-            }
-            if (has_next) {
-                setup_tile(next);
-                gload(0, SetTag<0>{});
-            }
-            compute();
-            lds_store(cur ^ 1, SetTag<1>{});
-            __syncthreads();
-            cur ^= 1;
-            if (has_next) gload(1, SetTag<1>{});
-            compute();
-            __syncthreads();
+            });
         } else {
             for (int t = 0; t < nk; ++t) {
                 const bool more = (t + 1) < nk;
@@ -432,14 +438,16 @@ static int persistent_grid(K kernel, int nblk, int& cached, int threads) {
 
 // AMAX: the epilogue also emits per-tile row maxima (its own kernel instantiation, so that profiles show the
 // vocabulary projection of greedy decoding under its own name).
-template <int BM, int BN, int WM, int WN, int KSPLIT, int KU = 1, bool VEC = true, bool PF2 = false, bool AMAX = false>
+template <int BM, int BN, int WM, int WN, int KSPLIT, int KU = 1, bool VEC = true, int PF = 1, bool AMAX = false>
 static int launch_cfg(ConvParams& p, hipStream_t st) {
-    if (PF2 && (((p.K + BK * KSPLIT * KU - 1) / (BK * KSPLIT * KU)) & 1)) {
+    if (PF > 1 && (((p.K + BK * KSPLIT * KU - 1) / (BK * KSPLIT * KU)) % PF)) {
         set_error("conv_igemm: this tile configuration needs an even number of K steps");
         return ICAP_ERR_ARG;
     }
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
+    p.tiles_m = tiles_m;
+    p.m_fast = (long long)p.Cout * p.K > (long long)p.B * p.H * p.W * p.Cin ? 1 : 0;
     const long long blocks = (long long)tiles_m * p.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         set_error("conv_igemm: grid of %lld workgroups out of range", blocks);
@@ -451,7 +459,7 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
 #define ICAP_LAUNCH(O_, G_)                                                                          \
     do {                                                                                             \
         static int cached = 0;                                                                       \
-        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC, PF2, AMAX>;                               \
+        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC, PF, AMAX>;                               \
         hipLaunchKernelGGL(kern, dim3((unsigned)persistent_grid(kern, p.nblk, cached, (int)block.x)), block, 0, st, p); \
     } while (0)
     if (one && p.gate) ICAP_LAUNCH(true, true);
@@ -493,9 +501,13 @@ static const TileCfg kCfgs[] = {
     {128, 64, 2, launch_cfg<128, 64, 2, 2, 2, 2>},  // 19
     {32, 64, 4, launch_cfg<32, 64, 1, 2, 4, 2>},    // 20
     {32, 32, 8, launch_cfg<32, 32, 1, 1, 8, 1>},    // 21
-    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 2, true, true>},    // 22: two K slices in flight (even step counts only)
-    {32, 32, 4, launch_cfg<32, 32, 1, 1, 4, 1, true, true>},    // 23
-    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 1, true, true>},    // 24
+    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 2, true, 2>},    // 22: two K slices in flight (even step counts only)
+    {32, 32, 4, launch_cfg<32, 32, 1, 1, 4, 1, true, 2>},    // 23
+    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 1, true, 2>},    // 24
+    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 1, true, 4>},    // 25: four K slices in flight
+    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 1, true, 8>},    // 26: eight
+    {128, 64, 1, launch_cfg<128, 64, 2, 2, 1, 1, true, 4>},  // 27
+    {32, 32, 4, launch_cfg<32, 32, 1, 1, 4, 1, true, 4>},    // 28
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -543,7 +555,7 @@ static ConvParams make_params(const float* x, const float* w, const float* scale
                               const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
                               int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act) {
     ConvParams p{x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW,
-                 stride, pad_t, pad_l, Ho, Wo, act, B * Ho * Wo, KH * KW * Cin, Cout, 0, 0, 0, nullptr, nullptr};
+                 stride, pad_t, pad_l, Ho, Wo, act, B * Ho * Wo, KH * KW * Cin, Cout, 0, 0, 0, 0, 0, nullptr, nullptr};
     p.vec_ok = (Cout % 4 == 0) && aligned16(y) && (!residual || aligned16(residual)) &&
                (!scale || aligned16(scale)) && (!bias || aligned16(bias));
     return p;
@@ -646,8 +658,14 @@ int linear_argmax_f32(const float* x, const float* w, const float* scale, const 
     p.y = y;
     p.amax_val = part_val;
     p.amax_idx = part_idx;
-    if ((((K + BK - 1) / BK) & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, true, true>(p, st);
-    return launch_cfg<64, 64, 2, 2, 1, 2, true, false, true>(p, st);
+    const int ksteps = (K + BK - 1) / BK;
+    if (const char* e = getenv("ICAP_AMAX_PF")) {
+        const int f = atoi(e);
+        if (f == 8 && ksteps % 8 == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 8, true>(p, st);
+        if (f == 4 && ksteps % 4 == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 4, true>(p, st);
+    }
+    if ((ksteps & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 2, true>(p, st);
+    return launch_cfg<64, 64, 2, 2, 1, 2, true, 1, true>(p, st);
 }
 
 int conv_igemm_tuned_cfg(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo) {

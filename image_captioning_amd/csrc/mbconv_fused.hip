@@ -1,0 +1,282 @@
+// Fused MBConv front half: 1x1 expand convolution + BatchNorm + swish + depthwise KSxKS convolution +
+// BatchNorm + swish (+ the per-channel sums squeeze-excite needs), without the expanded tensor ever
+// reaching HBM.  In EfficientNet-B0's early blocks that tensor is 6x the block's input and its write +
+// re-read dominates the time of the two separate kernels.
+//
+// A workgroup (4 waves) owns one TH x TW tile of output pixels of one image.  The input pixels the tile's
+// depthwise windows cover (IH x IW, with halo) are the rows of a small GEMM against the expand weights:
+//   * each wave keeps the A fragments of its 32-pixel row blocks in registers for the whole kernel
+//     (v_mfma_f32_32x32x2_f32: lane (r, h) supplies pixel r, input channels h*CIN/2 ...),
+//   * per 32-channel chunk: B fragments straight from the (L2-resident) weights, CIN/2 MFMAs per row block,
+//     BatchNorm + swish on the accumulators, zero for pixels outside the image (the depthwise convolution
+//     pads the EXPANDED activations with zeros), result to LDS as E[pixel][32 channels];
+//   * depthwise phase: a thread owns a channel quad and a strip of SW output pixels, walks the filter rows
+//     over E with 16-byte LDS reads, applies BatchNorm + swish and writes 16 B per lane along the channel axis.
+// Several workgroups share a CU (E is 40-60 KB), so one workgroup's MFMA phase overlaps another's depthwise
+// phase and the global stores.
+#include "common.hpp"
+
+namespace icap {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int XD_CC = 32;            // expanded channels per chunk (one MFMA column block)
+constexpr int XD_LDE = XD_CC + 4;    // padded row of E (16-byte aligned rows, consecutive pixels start 4 banks apart)
+
+// Workgroups whose LDS footprint fits a CU three times are compiled for three waves per SIMD, the others for two.
+template <int KS, int S, int TH, int TW>
+constexpr int xd_waves() {
+    return ((((TH - 1) * S + KS) * ((TW - 1) * S + KS) + 31) / 32) * 32 * XD_LDE * 4 + 2 * (KS * KS + 2) * 128 + 512 <= 160 * 1024 / 3 ? 3 : 2;
+}
+
+template <int CIN, int KS, int S, int TH, int TW, int SW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS, S, TH, TW>()))) void expand_dw_kernel(
+    const float* __restrict__ x, const float* __restrict__ we, const float* __restrict__ es, const float* __restrict__ eb,
+    const float* __restrict__ wd, const float* __restrict__ dsc, const float* __restrict__ dbi, float* __restrict__ y,
+    float* __restrict__ partial, int H, int W, int Cexp, int pad_t, int pad_l, int Ho, int Wo, int tiles_w, int cpg) {
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS, P = IH * IW;
+    constexpr int MB = (P + 31) / 32;          // 32-pixel row blocks
+    constexpr int NRB = (MB + 3) / 4;          // row blocks per wave
+    constexpr int KH2 = CIN / 2;               // input channels per lane half
+    constexpr int SPR = (TW + SW - 1) / SW;    // strips per output row
+    constexpr int NSTRIP = TH * SPR;
+    constexpr int NIN = (SW - 1) * S + KS;     // E columns feeding one strip
+    static_assert(CIN % 8 == 0, "each lane half reads whole float4s");
+
+    __shared__ __attribute__((aligned(16))) float E[MB * 32 * XD_LDE];
+    __shared__ float4 red[4][8];
+    // depthwise weights (KS*KS rows), folded-BN scale and bias (2 rows) of a 32-channel chunk, double buffered: the
+    // next chunk's rows are fetched into a register at the top of a chunk and stored behind its MFMA phase
+    constexpr int WROWS = KS * KS + 2;
+    static_assert(WROWS * 8 <= 256, "one float4 of the chunk's depthwise parameters per thread");
+    __shared__ float4 Wl[2][WROWS][8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int th_i = tile / tiles_w;
+    const int ho0 = th_i * TH, wo0 = (tile - th_i * tiles_w) * TW;
+    const int hi0 = ho0 * S - pad_t, wi0 = wo0 * S - pad_l;
+
+    // ---- A fragments: this wave's pixels, all CIN input channels split over the two lane halves ----
+    float af[NRB][KH2];
+    unsigned rowmask[NRB];
+#pragma unroll
+    for (int i = 0; i < NRB; ++i) {
+        const int pi = (wave + 4 * i) * 32 + lr;
+        const int ph = pi / IW, pw = pi - ph * IW;
+        const int hi = hi0 + ph, wi = wi0 + pw;
+        const bool ok = pi < P && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const float* src = ok ? x + (((size_t)b * H + hi) * W + wi) * CIN + lh * KH2 : x;
+#pragma unroll
+        for (int k = 0; k < KH2; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + k);
+            af[i][k] = ok ? v.x : 0.f; af[i][k + 1] = ok ? v.y : 0.f; af[i][k + 2] = ok ? v.z : 0.f; af[i][k + 3] = ok ? v.w : 0.f;
+        }
+        rowmask[i] = (unsigned)__ballot(ok);   // lanes 0..31 are the lh = 0 copy of rows 0..31
+    }
+
+    const int nchunks = (Cexp + XD_CC - 1) / XD_CC;
+    const int ch_end = min(nchunks, ((int)blockIdx.z + 1) * cpg);
+    const int q = tid & 7, sidx = tid >> 3;
+    const size_t ybase = (size_t)b * Ho * Wo;
+
+    // Per-chunk parameters are fetched one chunk ahead so that no phase waits for a global load it has just issued.
+    float bf[KH2], sc, bi;
+    auto load_expand_params = [&](int ch, float (&f)[KH2], float& s_, float& b_) {
+        const int cn = ch * XD_CC + lr;
+        const bool cok = cn < Cexp;
+        const float* wsrc = we + (size_t)(cok ? cn : 0) * CIN + lh * KH2;
+#pragma unroll
+        for (int k = 0; k < KH2; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(wsrc + k);
+            f[k] = v.x; f[k + 1] = v.y; f[k + 2] = v.z; f[k + 3] = v.w;
+        }
+        s_ = cok ? (es ? es[cn] : 1.f) : 0.f;
+        b_ = cok ? (eb ? eb[cn] : 0.f) : 0.f;
+    };
+    // thread t < WROWS*8 owns float4 (row t/8, quad t%8) of the chunk's depthwise parameter block
+    const int wrow = tid >> 3;
+    auto load_dw_params = [&](int ch) -> float4 {
+        const int c = ch * XD_CC + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wrow < WROWS && c < Cexp) {
+            if (wrow < KS * KS) v = *reinterpret_cast<const float4*>(wd + (size_t)wrow * Cexp + c);
+            else if (wrow == KS * KS) v = dsc ? *reinterpret_cast<const float4*>(dsc + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            else v = dbi ? *reinterpret_cast<const float4*>(dbi + c) : v;
+        }
+        return v;
+    };
+    const int ch_begin = blockIdx.z * cpg;
+    load_expand_params(ch_begin, bf, sc, bi);
+    if (wrow < WROWS) Wl[ch_begin & 1][wrow][q] = load_dw_params(ch_begin);
+
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int c0 = ch * XD_CC;
+        const int chn = ch + 1 < ch_end ? ch + 1 : ch;
+        float bfn[KH2], scn, bin;
+        load_expand_params(chn, bfn, scn, bin);
+        const float4 wln = load_dw_params(chn);
+        // ---- expand: E = swish(bn(A W^T)) for 32 channels ----
+        {
+#pragma unroll
+            for (int i = 0; i < NRB; ++i) {
+                const int rb = wave + 4 * i;
+                if (rb < MB) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KH2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[s], acc, 0, 0, 0);
+                    const unsigned mask = rowmask[i];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        float v = fmaf(acc[e], sc, bi);
+                        v = v * sigmoid_fast(v);
+                        E[(rb * 32 + row) * XD_LDE + lr] = ((mask >> row) & 1u) ? v : 0.f;
+                    }
+                }
+            }
+        }
+        if (wrow < WROWS) Wl[(ch + 1) & 1][wrow][q] = wln;
+        __syncthreads();
+
+        // ---- depthwise over E ----
+        const int c = c0 + q * 4;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < Cexp) {
+            const float4 (*wl)[8] = Wl[ch & 1];
+            const float4 sc4 = wl[KS * KS][q], bi4 = wl[KS * KS + 1][q];
+            for (int st = sidx; st < NSTRIP; st += 32) {
+                const int ro = st / SPR;
+                const int so = (st - ro * SPR) * SW;
+                float4 acc[SW];
+#pragma unroll
+                for (int o = 0; o < SW; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1   // a rolled filter-row loop keeps one row of weights live instead of KS*KS hoisted ones
+                for (int r = 0; r < KS; ++r) {
+                    float4 wr[KS];
+#pragma unroll
+                    for (int t = 0; t < KS; ++t) wr[t] = wl[r * KS + t][q];
+                    const int rowbase = (ro * S + r) * IW;
+                    float4 v[NIN];
+#pragma unroll
+                    for (int j = 0; j < NIN; ++j) {
+                        int col = so * S + j;
+                        if constexpr (TW % SW != 0) col = col < IW ? col : IW - 1;   // only outputs past the tile edge use these
+                        v[j] = *reinterpret_cast<const float4*>(&E[(rowbase + col) * XD_LDE + q * 4]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NIN; ++j)
+#pragma unroll
+                        for (int o = 0; o < SW; ++o) {
+                            const int t = j - o * S;
+                            if (t >= 0 && t < KS) {
+                                acc[o].x = fmaf(v[j].x, wr[t].x, acc[o].x); acc[o].y = fmaf(v[j].y, wr[t].y, acc[o].y);
+                                acc[o].z = fmaf(v[j].z, wr[t].z, acc[o].z); acc[o].w = fmaf(v[j].w, wr[t].w, acc[o].w);
+                            }
+                        }
+                }
+                const int ho = ho0 + ro;
+#pragma unroll
+                for (int o = 0; o < SW; ++o) {
+                    const int wl = so + o, wo = wo0 + wl;
+                    if (wl < TW && ho < Ho && wo < Wo) {
+                        float4 u;
+                        u.x = fmaf(acc[o].x, sc4.x, bi4.x); u.y = fmaf(acc[o].y, sc4.y, bi4.y);
+                        u.z = fmaf(acc[o].z, sc4.z, bi4.z); u.w = fmaf(acc[o].w, sc4.w, bi4.w);
+                        u.x *= sigmoid_fast(u.x); u.y *= sigmoid_fast(u.y); u.z *= sigmoid_fast(u.z); u.w *= sigmoid_fast(u.w);
+                        *reinterpret_cast<float4*>(y + (ybase + (size_t)ho * Wo + wo) * Cexp + c) = u;
+                        sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
+                    }
+                }
+            }
+        }
+        if (partial) {
+            // per-channel sum over the tile in a fixed order: lanes with equal q inside a wave, then the four waves
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                sum.x += __shfl_xor(sum.x, off, 64); sum.y += __shfl_xor(sum.y, off, 64);
+                sum.z += __shfl_xor(sum.z, off, 64); sum.w += __shfl_xor(sum.w, off, 64);
+            }
+            if (lane < 8) red[wave][lane] = sum;
+        }
+        __syncthreads();   // E is free for the next chunk; red is complete
+        if (partial && tid < 8 && c < Cexp) {
+            float4 t = red[0][tid];
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) { t.x += red[w2][tid].x; t.y += red[w2][tid].y; t.z += red[w2][tid].z; t.w += red[w2][tid].w; }
+            *reinterpret_cast<float4*>(partial + ((size_t)b * gridDim.x + tile) * Cexp + c) = t;
+        }
+#pragma unroll
+        for (int k = 0; k < KH2; ++k) bf[k] = bfn[k];
+        sc = scn; bi = bin;
+    }
+}
+
+struct XdCfg { int cin, ks, s, th, tw; };
+// One tile shape per (input channels, filter, stride) of EfficientNet-B0's expanding blocks.
+static const XdCfg kXd[] = {
+    {16, 3, 2, 8, 8}, {24, 3, 1, 14, 14}, {24, 5, 2, 7, 7}, {40, 5, 1, 14, 14}, {40, 3, 2, 7, 7},
+};
+
+static const XdCfg* xd_find(int Cin, int KS, int stride) {
+    for (const XdCfg& c : kXd)
+        if (c.cin == Cin && c.ks == KS && c.s == stride) return &c;
+    return nullptr;
+}
+
+// Number of per-image partial-sum chunks the fused kernel writes, or -1 when this layer shape has no fused kernel.
+int expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int stride) {
+    const XdCfg* c = xd_find(Cin, KS, stride);
+    if (!c || Ho <= 0 || Wo <= 0 || Cexp <= 0 || Cexp % 4) return -1;
+    return ((Ho + c->th - 1) / c->th) * ((Wo + c->tw - 1) / c->tw);
+}
+
+int expand_dwconv_f32(const float* x, const float* we, const float* es, const float* eb, const float* wd, const float* ds,
+                      const float* db, float* y, float* partial, int B, int H, int W, int Cin, int Cexp, int KS, int stride,
+                      int pad_t, int pad_l, int Ho, int Wo, hipStream_t st) {
+    if (!x || !we || !wd || !y || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || pad_t < 0 || pad_l < 0) {
+        set_error("expand_dwconv: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    const XdCfg* c = xd_find(Cin, KS, stride);
+    if (!c || Cexp <= 0 || Cexp % 4) {
+        set_error("expand_dwconv: no fused kernel for Cin=%d, %dx%d stride %d, Cexp=%d", Cin, KS, KS, stride, Cexp);
+        return ICAP_ERR_ARG;
+    }
+    if ((long long)(Ho - 1) * stride - pad_t >= H || (long long)(Wo - 1) * stride - pad_l >= W) {
+        set_error("expand_dwconv: output %dx%d does not fit input %dx%d", Ho, Wo, H, W);
+        return ICAP_ERR_ARG;
+    }
+    if (!aligned16(x) || !aligned16(we) || !aligned16(wd) || !aligned16(y) || (partial && !aligned16(partial)) ||
+        (ds && !aligned16(ds)) || (db && !aligned16(db))) {
+        set_error("expand_dwconv: pointers must be 16-byte aligned");
+        return ICAP_ERR_ALIGN;
+    }
+    if (B > 65535) { set_error("expand_dwconv: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
+    const int tiles_w = (Wo + c->tw - 1) / c->tw;
+    const int ntiles = ((Ho + c->th - 1) / c->th) * tiles_w;
+    const int nchunks = (Cexp + XD_CC - 1) / XD_CC;
+    // enough workgroups to give every CU several: split the channel chunks over grid.z when tiles x images is small
+    long long wg = (long long)ntiles * B;
+    int zg = (int)((4096 + wg - 1) / wg);
+    zg = zg < 1 ? 1 : (zg > nchunks ? nchunks : zg);
+    const int cpg = (nchunks + zg - 1) / zg;
+    zg = (nchunks + cpg - 1) / cpg;
+    const dim3 grid(ntiles, B, zg), block(256);
+#define ICAP_XD(CIN_, KS_, S_, TH_, TW_, SW_)                                                                              \
+    hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_>), grid, block, 0, st, x, we, es, eb, wd, ds, db, y, \
+                       partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg)
+    if (Cin == 16) ICAP_XD(16, 3, 2, 8, 8, 2);
+    else if (Cin == 24 && KS == 3) ICAP_XD(24, 3, 1, 14, 14, 7);
+    else if (Cin == 24) ICAP_XD(24, 5, 2, 7, 7, 2);
+    else if (Cin == 40 && KS == 5) ICAP_XD(40, 5, 1, 14, 14, 7);
+    else ICAP_XD(40, 3, 2, 7, 7, 2);
+#undef ICAP_XD
+    return launch_status("expand_dwconv");
+}
+
+}  // namespace icap

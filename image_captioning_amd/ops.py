@@ -154,6 +154,37 @@ def dwconv2d(x, w, scale=None, bias=None, *, ks, stride=1, pad=(0, 0, 0, 0), act
     return y, partial
 
 
+def expand_dwconv_supported(H, W, Cin, Cexp, ks, stride, pad) -> bool:
+    """True when the fused expand + depthwise kernel covers this layer shape."""
+    pt, pb, pl, pr = pad
+    return N.load().icap_expand_dwconv_chunks(conv_out_size(H, ks, stride, pt, pb), conv_out_size(W, ks, stride, pl, pr),
+                                              Cin, Cexp, ks, stride) > 0
+
+
+def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, ks, stride=1, pad=(0, 0, 0, 0), want_partial=False):
+    """x [B,H,W,Cin], w_exp [Cexp,1,1,Cin] or [Cexp,Cin], w_dw [ks*ks, Cexp] -> (swish(bn(dw(swish(bn(expand(x)))))), partial)."""
+    B, H, W, Cin = x.shape
+    Cexp = w_exp.shape[0]
+    pt, pb, pl, pr = pad
+    Ho = conv_out_size(H, ks, stride, pt, pb)
+    Wo = conv_out_size(W, ks, stride, pl, pr)
+    if w_exp.numel() != Cexp * Cin or tuple(w_dw.shape) != (ks * ks, Cexp):
+        raise IcapError("expand_dwconv2d: weights must be [Cexp, Cin] and [ks*ks, Cexp]")
+    lib = N.load()
+    nch = lib.icap_expand_dwconv_chunks(Ho, Wo, Cin, Cexp, ks, stride)
+    if nch <= 0:
+        raise IcapError(f"expand_dwconv2d: no fused kernel for Cin={Cin}, {ks}x{ks} stride {stride}")
+    y = torch.empty((B, Ho, Wo, Cexp), device=x.device, dtype=torch.float32)
+    partial = torch.empty((B, nch, Cexp), device=x.device, dtype=torch.float32) if want_partial else None
+    span = _Span("expand_dwconv2d", (B, H, W, Cin, Cexp, ks, stride, Ho, Wo))
+    N.check(lib.icap_expand_dwconv_f32(_ck(x, "x"), _ck(w_exp, "w_exp"), _ck(exp_scale, "exp_scale"), _ck(exp_bias, "exp_bias"),
+                                       _ck(w_dw, "w_dw"), _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"), _ck(y, "y"),
+                                       _ck(partial, "partial"), B, H, W, Cin, Cexp, ks, stride, pt, pl, Ho, Wo, _stream()),
+            "expand_dwconv2d")
+    span.done()
+    return y, partial
+
+
 def se_gate(partial, hw: int, wr, br, we, be):
     B, nchunks, Cc = partial.shape
     S = wr.shape[0]

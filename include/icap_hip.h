@@ -80,6 +80,18 @@ int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const 
                       int Ho, int Wo, int act, void* stream);
 int icap_dwconv_chunks(int Ho, int Wo, int C, int KS, int stride);
 
+/* Fused MBConv front half: 1x1 expand convolution + folded BatchNorm + swish, then the depthwise KSxKS
+ * convolution + folded BatchNorm + swish, with the expanded activations kept on chip.  x [B][H][W][Cin],
+ * w_exp [Cexp][Cin], w_dw [KS*KS][Cexp], y [B][Ho][Wo][Cexp]; `partial` as in icap_dwconv2d_f32 with
+ * icap_expand_dwconv_chunks(...) chunks per image.  icap_expand_dwconv_chunks returns -1 for layer shapes that
+ * have no fused kernel (callers then run icap_conv2d_f32 + icap_dwconv2d_f32).  Replaces MBConv `_expand_conv` +
+ * `_bn0` + swish + `_depthwise_conv` + `_bn1` + swish of EfficientNet-B0 (transformer_word_level.py:13). */
+int icap_expand_dwconv_f32(const float* x, const float* w_exp, const float* exp_scale, const float* exp_bias,
+                           const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial,
+                           int B, int H, int W, int Cin, int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho,
+                           int Wo, void* stream);
+int icap_expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int stride);
+
 /* Squeeze-excite gate: gate[b][c] = sigmoid(We . swish(Wr . mean_hw(x) + br) + be),
  * from the chunk sums written by icap_dwconv2d_f32.  wr [S][C]; we [S][C] (the expand weight TRANSPOSED).
  * Replaces MBConv `_se_reduce` / `_se_expand` (transformer_word_level.py:13). */

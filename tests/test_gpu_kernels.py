@@ -113,6 +113,37 @@ def test_dwconv_and_se(C, H, W, ks, s, pad):
     close(gate, torch.sigmoid(sq @ we.t() + be), what="se gate")
 
 
+@pytest.mark.parametrize("Cin,Cexp,H,W,ks,s,pad", [(16, 96, 37, 41, 3, 2, (0, 1, 0, 1)), (24, 144, 28, 30, 3, 1, (1, 1, 1, 1)),
+                                                    (24, 144, 29, 27, 5, 2, (1, 2, 1, 2)), (40, 240, 28, 17, 5, 1, (2, 2, 2, 2)),
+                                                    (40, 240, 28, 28, 3, 2, (0, 1, 0, 1)), (16, 100, 16, 16, 3, 2, (0, 1, 0, 1))])
+def test_fused_expand_dwconv(Cin, Cexp, H, W, ks, s, pad):
+    """1x1 expand + BN + swish + depthwise + BN + swish in one kernel == the two torch convolutions; sizes that do not
+    divide the kernel's tiles, TF-'same' asymmetric padding, a channel count that is not a multiple of the 32-wide chunk."""
+    from image_captioning_amd import ops
+    d = dev()
+    B = 3
+    x = rnd(B, Cin, H, W, seed=1)
+    we = rnd(Cexp, Cin, 1, 1, seed=2, scale=Cin ** -0.5)
+    es, eb = torch.rand(Cexp, generator=torch.Generator().manual_seed(3)) + 0.5, rnd(Cexp, seed=4, scale=0.3)
+    wd = rnd(Cexp, 1, ks, ks, seed=5, scale=1.0 / ks)
+    dsc, dbi = torch.rand(Cexp, generator=torch.Generator().manual_seed(6)) + 0.5, rnd(Cexp, seed=7, scale=0.1)
+    e = F.conv2d(x, we) * es[None, :, None, None] + eb[None, :, None, None]
+    e = e * torch.sigmoid(e)
+    ref = F.conv2d(F.pad(e, (pad[2], pad[3], pad[0], pad[1])), wd, stride=s, groups=Cexp)
+    ref = ref * dsc[None, :, None, None] + dbi[None, :, None, None]
+    ref = ref * torch.sigmoid(ref)
+    assert ops.expand_dwconv_supported(H, W, Cin, Cexp, ks, s, pad)
+    y, part = ops.expand_dwconv2d(x.permute(0, 2, 3, 1).contiguous().to(d), we.view(Cexp, Cin).contiguous().to(d), es.to(d), eb.to(d),
+                                  wd.view(Cexp, ks * ks).t().contiguous().to(d), dsc.to(d), dbi.to(d), ks=ks, stride=s, pad=pad,
+                                  want_partial=True)
+    close(y.permute(0, 3, 1, 2), ref, what="expand+dwconv")
+    close(part.sum(1) / (ref.shape[2] * ref.shape[3]), ref.mean((2, 3)), what="expand+dwconv partial pool")
+    assert not ops.expand_dwconv_supported(14, 14, 80, 480, 3, 1, (1, 1, 1, 1))
+    with pytest.raises(ops.IcapError):
+        ops.expand_dwconv2d(torch.zeros(1, 14, 14, 80, device=d), torch.zeros(480, 80, device=d), None, None,
+                            torch.zeros(9, 480, device=d), None, None, ks=3, stride=1, pad=(1, 1, 1, 1))
+
+
 def test_pools():
     from image_captioning_amd import ops
     d = dev()

@@ -80,7 +80,13 @@ def expand_dw_work(sig):
             4.0 * (B * H * W * Cin + B * Ho * Wo * Cexp + Cexp * (Cin + ks * ks)))
 
 
-WORK = {"conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work, "expand_dwconv2d": expand_dw_work,
+def stem_dw_work(sig):
+    """(B, H, W, C, Hs, Ws, Ho, Wo): 3x3x3 stem + 3x3 depthwise; the 4-channel-padded image read once, the output written once."""
+    B, H, W, C, Hs, Ws, Ho, Wo = sig
+    return 2.0 * B * Hs * Ws * 27 * C + 2.0 * B * Ho * Wo * C * 9, 4.0 * (B * H * W * 4 + B * Ho * Wo * C)
+
+
+WORK = {"stem_dwconv2d": stem_dw_work, "conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work, "expand_dwconv2d": expand_dw_work,
         # training-step launches: (flops, algorithmic bytes)
         "gemm_nn": gemm_work, "gemm_tn": gemm_work,
         "col_reduce": lambda s: (2.0 * s[1] * s[2], 4.0 * s[1] * s[2] * (2 if s[0] >= 2 else 1)),

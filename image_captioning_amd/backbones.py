@@ -318,8 +318,18 @@ class EfficientNetB0(nn.Module):
         p = self._prep.get(self, self._build)
         x = ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)
         lo, hi = same_pad(3, 2)
-        x = ops.conv2d(x, p["stem_w"], *p["stem_sb"], stride=2, pad=(lo, hi, lo, hi), act=ops.ACT_SWISH)
-        for d in p["blocks"]:
+        blocks = p["blocks"]
+        d0 = blocks[0]
+        if d0["expand"] is None and d0["k"] == 3 and d0["stride"] == 1 and not d0["skip"]:
+            # the stem's 112x112x32 output feeds only block 0's depthwise convolution: both run in one kernel
+            h, part = ops.stem_dwconv2d(x, p["stem_w"], *p["stem_sb"], d0["dw_w"], *d0["dw_sb"], stem_pad=(lo, hi, lo, hi),
+                                        pad=(1, 1, 1, 1), want_partial=True)
+            gate = ops.se_gate(part, h.shape[1] * h.shape[2], *d0["se"])
+            x = ops.conv2d(h, d0["proj"][0], *d0["proj"][1], gate=gate)
+            blocks = blocks[1:]
+        else:
+            x = ops.conv2d(x, p["stem_w"], *p["stem_sb"], stride=2, pad=(lo, hi, lo, hi), act=ops.ACT_SWISH)
+        for d in blocks:
             inp = x
             h = x
             lo, hi = same_pad(d["k"], d["stride"])

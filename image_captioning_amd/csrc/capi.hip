@@ -34,6 +34,9 @@ int dwconv_chunks(int, int, int, int, int);
 int expand_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                       float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int expand_dwconv_chunks(int, int, int, int, int, int);
+int stem_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                    float*, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int stem_dwconv_chunks(int, int, int);
 int se_gate_f32(const float*, int, float, const float*, const float*, const float*, const float*, float*, int, int, int,
                 hipStream_t);
 int maxpool2d_f32(const float*, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -156,6 +159,16 @@ int icap_expand_dwconv_f32(const float* x, const float* w_exp, const float* exp_
     return expand_dwconv_f32(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, y, partial, B, H, W, Cin, Cexp, KS, stride,
                              pad_t, pad_l, Ho, Wo, (hipStream_t)stream);
 }
+
+int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias, const float* w_dw,
+                         const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int img_h, int img_w,
+                         int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,
+                         void* stream) {
+    return stem_dwconv_f32(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, y, partial, B, img_h, img_w, Hs, Ws, C,
+                           stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, (hipStream_t)stream);
+}
+
+int icap_stem_dwconv_chunks(int Ho, int Wo, int C) { return stem_dwconv_chunks(Ho, Wo, C); }
 
 int icap_expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int stride) {
     return expand_dwconv_chunks(Ho, Wo, Cin, Cexp, KS, stride);

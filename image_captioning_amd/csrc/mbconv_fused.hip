@@ -26,14 +26,19 @@ constexpr int XD_LDE = XD_CC + 4;    // padded row of E (16-byte aligned rows, c
 // Workgroups whose LDS footprint fits a CU three times are compiled for three waves per SIMD, the others for two.
 template <int KS, int S, int TH, int TW>
 constexpr int xd_waves() {
-    return ((((TH - 1) * S + KS) * ((TW - 1) * S + KS) + 31) / 32) * 32 * XD_LDE * 4 + 2 * (KS * KS + 2) * 128 + 512 <= 160 * 1024 / 3 ? 3 : 2;
+    return ((((TH - 1) * S + KS) * ((TW - 1) * S + KS) + 31) / 32) * 32 * XD_LDE * 4 + 2 * (KS * KS + 1) * 128 + 512 <= 160 * 1024 / 3 ? 3 : 2;
 }
 
-template <int CIN, int KS, int S, int TH, int TW, int SW>
+// STEM: the first convolution is not a 1x1 expand but EfficientNet's 3x3 stride-2 stem on the 4-channel-padded image
+// (x [B][img_h][img_w][4], we [Cexp][3][3][4]): the GEMM's K axis is the 36-element patch, padded to 40 (ten taps, five per
+// lane half, the tenth zero), gathered straight from the image; H x W is then the stem's OUTPUT size.
+template <int CIN, int KS, int S, int TH, int TW, int SW, bool STEM = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS, S, TH, TW>()))) void expand_dw_kernel(
     const float* __restrict__ x, const float* __restrict__ we, const float* __restrict__ es, const float* __restrict__ eb,
     const float* __restrict__ wd, const float* __restrict__ dsc, const float* __restrict__ dbi, float* __restrict__ y,
-    float* __restrict__ partial, int H, int W, int Cexp, int pad_t, int pad_l, int Ho, int Wo, int tiles_w, int cpg) {
+    float* __restrict__ partial, int H, int W, int Cexp, int pad_t, int pad_l, int Ho, int Wo, int tiles_w, int cpg,
+    int img_h, int img_w, int stem_pad_t, int stem_pad_l) {
+    static_assert(!STEM || CIN == 40, "the stem patch is 36 values padded to 40");
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS, P = IH * IW;
     constexpr int MB = (P + 31) / 32;          // 32-pixel row blocks
     constexpr int NRB = (MB + 3) / 4;          // row blocks per wave
@@ -45,9 +50,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
 
     __shared__ __attribute__((aligned(16))) float E[MB * 32 * XD_LDE];
     __shared__ float4 red[4][8];
-    // depthwise weights (KS*KS rows), folded-BN scale and bias (2 rows) of a 32-channel chunk, double buffered: the
-    // next chunk's rows are fetched into a register at the top of a chunk and stored behind its MFMA phase
-    constexpr int WROWS = KS * KS + 2;
+    // depthwise weights times the folded-BN scale (KS*KS rows) and the folded-BN bias (1 row) of a 32-channel chunk,
+    // double buffered: the next chunk's rows are fetched into a register at the top of a chunk and stored behind its
+    // MFMA phase
+    constexpr int WROWS = KS * KS + 1;
     static_assert(WROWS * 8 <= 256, "one float4 of the chunk's depthwise parameters per thread");
     __shared__ float4 Wl[2][WROWS][8];
 
@@ -68,13 +74,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
         const int ph = pi / IW, pw = pi - ph * IW;
         const int hi = hi0 + ph, wi = wi0 + pw;
         const bool ok = pi < P && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-        const float* src = ok ? x + (((size_t)b * H + hi) * W + wi) * CIN + lh * KH2 : x;
+        if constexpr (STEM) {
 #pragma unroll
-        for (int k = 0; k < KH2; k += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(src + k);
-            af[i][k] = ok ? v.x : 0.f; af[i][k + 1] = ok ? v.y : 0.f; af[i][k + 2] = ok ? v.z : 0.f; af[i][k + 3] = ok ? v.w : 0.f;
+            for (int j = 0; j < 5; ++j) {
+                const int tap = lh * 5 + j;                     // tap 9 does not exist: zero
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const int ih = hi * 2 - stem_pad_t + kh, iw = wi * 2 - stem_pad_l + kw;
+                const bool tok = ok && tap < 9 && (unsigned)ih < (unsigned)img_h && (unsigned)iw < (unsigned)img_w;
+                const float4 v = *reinterpret_cast<const float4*>(tok ? x + (((size_t)b * img_h + ih) * img_w + iw) * 4 : x);
+                af[i][4 * j] = tok ? v.x : 0.f; af[i][4 * j + 1] = tok ? v.y : 0.f; af[i][4 * j + 2] = tok ? v.z : 0.f; af[i][4 * j + 3] = tok ? v.w : 0.f;
+            }
+        } else {
+            const float* src = ok ? x + (((size_t)b * H + hi) * W + wi) * CIN + lh * KH2 : x;
+#pragma unroll
+            for (int k = 0; k < KH2; k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src + k);
+                af[i][k] = ok ? v.x : 0.f; af[i][k + 1] = ok ? v.y : 0.f; af[i][k + 2] = ok ? v.z : 0.f; af[i][k + 3] = ok ? v.w : 0.f;
+            }
         }
-        rowmask[i] = (unsigned)__ballot(ok);   // lanes 0..31 are the lh = 0 copy of rows 0..31
+        // bit r set: row r needs no zeroing (rows past the tile's last pixel are never read by the depthwise phase);
+        // lanes 0..31 are the lh = 0 copy of rows 0..31
+        rowmask[i] = (unsigned)__ballot(ok || pi >= P);
     }
 
     const int nchunks = (Cexp + XD_CC - 1) / XD_CC;
@@ -87,14 +107,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     auto load_expand_params = [&](int ch, float (&f)[KH2], float& s_, float& b_) {
         const int cn = ch * XD_CC + lr;
         const bool cok = cn < Cexp;
-        const float* wsrc = we + (size_t)(cok ? cn : 0) * CIN + lh * KH2;
-#pragma unroll
-        for (int k = 0; k < KH2; k += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(wsrc + k);
-            f[k] = v.x; f[k + 1] = v.y; f[k + 2] = v.z; f[k + 3] = v.w;
-        }
+        constexpr int WLD = STEM ? 36 : CIN;      // floats per weight row in memory
+        const float* wsrc = we + (size_t)(cok ? cn : 0) * WLD + lh * KH2;
         s_ = cok ? (es ? es[cn] : 1.f) : 0.f;
         b_ = cok ? (eb ? eb[cn] : 0.f) : 0.f;
+        // the folded-BN scale goes into the weights (a lane's B values all belong to its one output channel) and the
+        // bias into the initial accumulator, so the MFMA chain ends with the normalised value
+#pragma unroll
+        for (int k = 0; k < KH2; k += 4) {
+            const bool kok = !STEM || lh * KH2 + k < 36;
+            const float4 v = *reinterpret_cast<const float4*>(kok ? wsrc + k : we);
+            f[k] = kok ? v.x * s_ : 0.f; f[k + 1] = kok ? v.y * s_ : 0.f; f[k + 2] = kok ? v.z * s_ : 0.f; f[k + 3] = kok ? v.w * s_ : 0.f;
+        }
     };
     // thread t < WROWS*8 owns float4 (row t/8, quad t%8) of the chunk's depthwise parameter block
     const int wrow = tid >> 3;
@@ -102,9 +126,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
         const int c = ch * XD_CC + q * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (wrow < WROWS && c < Cexp) {
-            if (wrow < KS * KS) v = *reinterpret_cast<const float4*>(wd + (size_t)wrow * Cexp + c);
-            else if (wrow == KS * KS) v = dsc ? *reinterpret_cast<const float4*>(dsc + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-            else v = dbi ? *reinterpret_cast<const float4*>(dbi + c) : v;
+            if (wrow < KS * KS) {
+                v = *reinterpret_cast<const float4*>(wd + (size_t)wrow * Cexp + c);
+                if (dsc) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(dsc + c);
+                    v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
+                }
+            } else if (dbi) {
+                v = *reinterpret_cast<const float4*>(dbi + c);
+            }
         }
         return v;
     };
@@ -126,16 +156,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
                 if (rb < MB) {
                     f32x16 acc;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                    for (int e = 0; e < 16; ++e) acc[e] = bi;
 #pragma unroll
                     for (int s = 0; s < KH2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[s], acc, 0, 0, 0);
-                    const unsigned mask = rowmask[i];
+                    // swish stage by stage over all 16 accumulators, so that no exp2 / rcp result is needed right
+                    // after it is issued
+                    float r[16];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        float v = fmaf(acc[e], sc, bi);
-                        v = v * sigmoid_fast(v);
-                        E[(rb * 32 + row) * XD_LDE + lr] = ((mask >> row) & 1u) ? v : 0.f;
+                    for (int e = 0; e < 16; ++e) r[e] = __builtin_amdgcn_exp2f(acc[e] * -1.4426950408889634f);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) r[e] = __builtin_amdgcn_rcpf(r[e] + 1.f);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) r[e] *= acc[e];
+                    float* dst = &E[(rb * 32 + 4 * lh) * XD_LDE + lr];
+                    const unsigned mask = rowmask[i];
+                    if (mask == 0xffffffffu) {     // wave-uniform: no pixel of this row block lies outside the image
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * XD_LDE] = r[e];
+                    } else {
+                        const unsigned lmask = mask >> (4 * lh);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            dst[((e & 3) + 8 * (e >> 2)) * XD_LDE] = ((lmask >> ((e & 3) + 8 * (e >> 2))) & 1u) ? r[e] : 0.f;
+                        }
                     }
                 }
             }
@@ -148,13 +191,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < Cexp) {
             const float4 (*wl)[8] = Wl[ch & 1];
-            const float4 sc4 = wl[KS * KS][q], bi4 = wl[KS * KS + 1][q];
+            const float4 bi4 = wl[KS * KS][q];
             for (int st = sidx; st < NSTRIP; st += 32) {
                 const int ro = st / SPR;
                 const int so = (st - ro * SPR) * SW;
                 float4 acc[SW];
 #pragma unroll
-                for (int o = 0; o < SW; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int o = 0; o < SW; ++o) acc[o] = bi4;
 #pragma unroll 1   // a rolled filter-row loop keeps one row of weights live instead of KS*KS hoisted ones
                 for (int r = 0; r < KS; ++r) {
                     float4 wr[KS];
@@ -184,9 +227,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
                 for (int o = 0; o < SW; ++o) {
                     const int wl = so + o, wo = wo0 + wl;
                     if (wl < TW && ho < Ho && wo < Wo) {
-                        float4 u;
-                        u.x = fmaf(acc[o].x, sc4.x, bi4.x); u.y = fmaf(acc[o].y, sc4.y, bi4.y);
-                        u.z = fmaf(acc[o].z, sc4.z, bi4.z); u.w = fmaf(acc[o].w, sc4.w, bi4.w);
+                        float4 u = acc[o];
                         u.x *= sigmoid_fast(u.x); u.y *= sigmoid_fast(u.y); u.z *= sigmoid_fast(u.z); u.w *= sigmoid_fast(u.w);
                         *reinterpret_cast<float4*>(y + (ybase + (size_t)ho * Wo + wo) * Cexp + c) = u;
                         sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
@@ -219,7 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
 struct XdCfg { int cin, ks, s, th, tw; };
 // One tile shape per (input channels, filter, stride) of EfficientNet-B0's expanding blocks.
 static const XdCfg kXd[] = {
-    {16, 3, 2, 8, 8}, {24, 3, 1, 14, 14}, {24, 5, 2, 7, 7}, {40, 5, 1, 14, 14}, {40, 3, 2, 7, 7},
+    {16, 3, 2, 7, 8}, {24, 3, 1, 14, 14}, {24, 5, 2, 7, 7}, {40, 5, 1, 14, 14}, {40, 3, 2, 7, 7},
 };
 
 static const XdCfg* xd_find(int Cin, int KS, int stride) {
@@ -269,14 +310,51 @@ int expand_dwconv_f32(const float* x, const float* we, const float* es, const fl
     const dim3 grid(ntiles, B, zg), block(256);
 #define ICAP_XD(CIN_, KS_, S_, TH_, TW_, SW_)                                                                              \
     hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_>), grid, block, 0, st, x, we, es, eb, wd, ds, db, y, \
-                       partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg)
-    if (Cin == 16) ICAP_XD(16, 3, 2, 8, 8, 2);
+                       partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0)
+    if (Cin == 16) ICAP_XD(16, 3, 2, 7, 8, 2);
     else if (Cin == 24 && KS == 3) ICAP_XD(24, 3, 1, 14, 14, 7);
     else if (Cin == 24) ICAP_XD(24, 5, 2, 7, 7, 2);
     else if (Cin == 40 && KS == 5) ICAP_XD(40, 5, 1, 14, 14, 7);
     else ICAP_XD(40, 3, 2, 7, 7, 2);
 #undef ICAP_XD
     return launch_status("expand_dwconv");
+}
+
+// EfficientNet stem (3x3 stride 2 on the 4-channel-padded image, BN, swish) fused with block 0's depthwise 3x3 stride 1
+// (+ BN + swish + squeeze-excite partial sums): x [B][img_h][img_w][4], w_stem [C][3][3][4], y [B][Ho][Wo][C].
+constexpr int STEM_TH = 14, STEM_TW = 14;
+
+int stem_dwconv_chunks(int Ho, int Wo, int C) {
+    if (Ho <= 0 || Wo <= 0 || C <= 0 || C % 4) return -1;
+    return ((Ho + STEM_TH - 1) / STEM_TH) * ((Wo + STEM_TW - 1) / STEM_TW);
+}
+
+int stem_dwconv_f32(const float* x, const float* ws, const float* ss, const float* sb, const float* wd, const float* ds,
+                    const float* db, float* y, float* partial, int B, int img_h, int img_w, int Hs, int Ws, int C,
+                    int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo, hipStream_t st) {
+    if (!x || !ws || !wd || !y || B <= 0 || img_h <= 0 || img_w <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 ||
+        C % 4 || stem_pad_t < 0 || stem_pad_l < 0 || pad_t < 0 || pad_l < 0) {
+        set_error("stem_dwconv: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if ((long long)(Hs - 1) * 2 - stem_pad_t >= img_h || (long long)(Ws - 1) * 2 - stem_pad_l >= img_w ||
+        (long long)(Ho - 1) - pad_t >= Hs || (long long)(Wo - 1) - pad_l >= Ws) {
+        set_error("stem_dwconv: output sizes do not fit the image");
+        return ICAP_ERR_ARG;
+    }
+    if (!aligned16(x) || !aligned16(ws) || !aligned16(wd) || !aligned16(y) || (partial && !aligned16(partial)) ||
+        (ds && !aligned16(ds)) || (db && !aligned16(db))) {
+        set_error("stem_dwconv: pointers must be 16-byte aligned");
+        return ICAP_ERR_ALIGN;
+    }
+    if (B > 65535) { set_error("stem_dwconv: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
+    const int tiles_w = (Wo + STEM_TW - 1) / STEM_TW;
+    const int ntiles = ((Ho + STEM_TH - 1) / STEM_TH) * tiles_w;
+    const int nchunks = (C + XD_CC - 1) / XD_CC;
+    const dim3 grid(ntiles, B, 1), block(256);
+    hipLaunchKernelGGL((expand_dw_kernel<40, 3, 1, STEM_TH, STEM_TW, 7, true>), grid, block, 0, st, x, ws, ss, sb, wd, ds, db, y,
+                       partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l);
+    return launch_status("stem_dwconv");
 }
 
 }  // namespace icap

@@ -185,6 +185,29 @@ def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, k
     return y, partial
 
 
+def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, stem_pad=(0, 1, 0, 1), pad=(1, 1, 1, 1), want_partial=False):
+    """x [B,H,W,4] (image, channels padded to 4), w_stem [C,3,3,4], w_dw [9, C] ->
+    (swish(bn(dw3x3(swish(bn(conv3x3 stride 2 (x)))))), partial): EfficientNet stem + block 0's depthwise convolution."""
+    B, H, W, c4 = x.shape
+    Cc = w_stem.shape[0]
+    if c4 != 4 or tuple(w_stem.shape[1:]) != (3, 3, 4) or tuple(w_dw.shape) != (9, Cc):
+        raise IcapError("stem_dwconv2d: x must be [B,H,W,4], w_stem [C,3,3,4], w_dw [9,C]")
+    Hs = conv_out_size(H, 3, 2, stem_pad[0], stem_pad[1])
+    Ws = conv_out_size(W, 3, 2, stem_pad[2], stem_pad[3])
+    Ho = conv_out_size(Hs, 3, 1, pad[0], pad[1])
+    Wo = conv_out_size(Ws, 3, 1, pad[2], pad[3])
+    lib = N.load()
+    y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    partial = torch.empty((B, lib.icap_stem_dwconv_chunks(Ho, Wo, Cc), Cc), device=x.device, dtype=torch.float32) if want_partial else None
+    span = _Span("stem_dwconv2d", (B, H, W, Cc, Hs, Ws, Ho, Wo))
+    N.check(lib.icap_stem_dwconv_f32(_ck(x, "x"), _ck(w_stem, "w_stem"), _ck(stem_scale, "stem_scale"), _ck(stem_bias, "stem_bias"),
+                                     _ck(w_dw, "w_dw"), _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"), _ck(y, "y"),
+                                     _ck(partial, "partial"), B, H, W, Hs, Ws, Cc, stem_pad[0], stem_pad[2], pad[0], pad[2], Ho, Wo,
+                                     _stream()), "stem_dwconv2d")
+    span.done()
+    return y, partial
+
+
 def se_gate(partial, hw: int, wr, br, we, be):
     B, nchunks, Cc = partial.shape
     S = wr.shape[0]

@@ -92,6 +92,18 @@ int icap_expand_dwconv_f32(const float* x, const float* w_exp, const float* exp_
                            int Wo, void* stream);
 int icap_expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int stride);
 
+/* EfficientNet-B0 stem fused with block 0's depthwise convolution: 3x3 stride-2 convolution of the 4-channel-padded
+ * image x [B][img_h][img_w][4] with w_stem [C][3][3][4] (TF-"same" padding stem_pad_t / stem_pad_l at the top / left,
+ * output Hs x Ws), folded BatchNorm, swish; then the depthwise 3x3 stride-1 convolution w_dw [9][C] (padding pad_t /
+ * pad_l), folded BatchNorm, swish -> y [B][Ho][Wo][C]; `partial` as in icap_dwconv2d_f32 with
+ * icap_stem_dwconv_chunks(Ho, Wo, C) chunks per image.  Replaces `_conv_stem` + `_bn0` + swish and block 0's
+ * `_depthwise_conv` + `_bn1` + swish (transformer_word_level.py:13). */
+int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias,
+                         const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial, int B,
+                         int img_h, int img_w, int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l,
+                         int Ho, int Wo, void* stream);
+int icap_stem_dwconv_chunks(int Ho, int Wo, int C);
+
 /* Squeeze-excite gate: gate[b][c] = sigmoid(We . swish(Wr . mean_hw(x) + br) + be),
  * from the chunk sums written by icap_dwconv2d_f32.  wr [S][C]; we [S][C] (the expand weight TRANSPOSED).
  * Replaces MBConv `_se_reduce` / `_se_expand` (transformer_word_level.py:13). */

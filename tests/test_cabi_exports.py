@@ -37,5 +37,6 @@ def test_argument_checks_need_no_gpu():
     assert rc == 1 and b"null" in lib.icap_last_error()
     assert lib.icap_gemv_blocks(6756) > 0
     assert lib.icap_dwconv_chunks(112, 112, 32, 3, 1) > 0 and lib.icap_dwconv_chunks(7, 7, 1152, 5, 1) == 7
-    assert lib.icap_expand_dwconv_chunks(56, 56, 16, 96, 3, 2) == 49 and lib.icap_expand_dwconv_chunks(14, 14, 80, 480, 3, 1) == -1
+    assert lib.icap_expand_dwconv_chunks(56, 56, 16, 96, 3, 2) == 56 and lib.icap_expand_dwconv_chunks(14, 14, 80, 480, 3, 1) == -1
+    assert lib.icap_stem_dwconv_chunks(112, 112, 32) == 64
     assert lib.icap_greedy_tfm_ws_floats(8, 512, 2048, 6756) > 8 * 512 * 4

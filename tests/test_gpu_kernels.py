@@ -144,6 +144,30 @@ def test_fused_expand_dwconv(Cin, Cexp, H, W, ks, s, pad):
                             torch.zeros(9, 480, device=d), None, None, ks=3, stride=1, pad=(1, 1, 1, 1))
 
 
+@pytest.mark.parametrize("H,W", [(56, 56), (45, 61)])
+def test_fused_stem_dwconv(H, W):
+    """EfficientNet stem (3x3 stride 2, TF-'same') + BN + swish + block 0's depthwise 3x3 + BN + swish in one kernel."""
+    from image_captioning_amd import ops
+    d = dev()
+    B, C = 3, 32
+    x = rnd(B, 3, H, W, seed=1)
+    ws = rnd(C, 3, 3, 3, seed=2, scale=27 ** -0.5)
+    ss, sb = torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5, rnd(C, seed=4, scale=0.3)
+    wd = rnd(C, 1, 3, 3, seed=5, scale=1.0 / 3)
+    dsc, dbi = torch.rand(C, generator=torch.Generator().manual_seed(6)) + 0.5, rnd(C, seed=7, scale=0.1)
+    sp = (0, 2 - (H % 2), 0, 2 - (W % 2))                      # TF-'same' for a 3x3 stride-2 convolution
+    e = F.conv2d(F.pad(x, (sp[2], sp[3], sp[0], sp[1])), ws, stride=2) * ss[None, :, None, None] + sb[None, :, None, None]
+    e = e * torch.sigmoid(e)
+    ref = F.conv2d(e, wd, padding=1, groups=C) * dsc[None, :, None, None] + dbi[None, :, None, None]
+    ref = ref * torch.sigmoid(ref)
+    x4 = ops.nchw_to_nhwc_pad(x.to(d), 4)
+    ws4 = F.pad(ws.permute(0, 2, 3, 1), (0, 1)).contiguous()
+    y, part = ops.stem_dwconv2d(x4, ws4.to(d), ss.to(d), sb.to(d), wd.view(C, 9).t().contiguous().to(d), dsc.to(d), dbi.to(d),
+                                stem_pad=sp, pad=(1, 1, 1, 1), want_partial=True)
+    close(y.permute(0, 3, 1, 2), ref, what="stem+dwconv")
+    close(part.sum(1) / (ref.shape[2] * ref.shape[3]), ref.mean((2, 3)), what="stem+dwconv partial pool")
+
+
 def test_pools():
     from image_captioning_amd import ops
     d = dev()

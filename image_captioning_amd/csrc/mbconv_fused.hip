@@ -66,30 +66,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     const int hi0 = ho0 * S - pad_t, wi0 = wo0 * S - pad_l;
 
     // ---- A fragments: this wave's pixels, all CIN input channels split over the two lane halves ----
+    // Nothing here consumes a loaded value (a consumer would wait for the load where it is issued): pixels outside the
+    // image read a valid dummy address and their rows are zeroed after the MFMAs; only the stem's image-border taps need
+    // true zeros, applied right before the fragment's first use (tapmask bit j: tap j of this lane is real).
     float af[NRB][KH2];
-    unsigned rowmask[NRB];
+    unsigned rowmask[NRB], tapmask[NRB];
 #pragma unroll
     for (int i = 0; i < NRB; ++i) {
         const int pi = (wave + 4 * i) * 32 + lr;
         const int ph = pi / IW, pw = pi - ph * IW;
         const int hi = hi0 + ph, wi = wi0 + pw;
         const bool ok = pi < P && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        tapmask[i] = 0x1f;
         if constexpr (STEM) {
+            tapmask[i] = 0;
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                const int tap = lh * 5 + j;                     // tap 9 does not exist: zero
+                const int tap = lh * 5 + j;                     // tap 9 does not exist: its weights are zero
                 const int kh = tap / 3, kw = tap - kh * 3;
                 const int ih = hi * 2 - stem_pad_t + kh, iw = wi * 2 - stem_pad_l + kw;
                 const bool tok = ok && tap < 9 && (unsigned)ih < (unsigned)img_h && (unsigned)iw < (unsigned)img_w;
                 const float4 v = *reinterpret_cast<const float4*>(tok ? x + (((size_t)b * img_h + ih) * img_w + iw) * 4 : x);
-                af[i][4 * j] = tok ? v.x : 0.f; af[i][4 * j + 1] = tok ? v.y : 0.f; af[i][4 * j + 2] = tok ? v.z : 0.f; af[i][4 * j + 3] = tok ? v.w : 0.f;
+                af[i][4 * j] = v.x; af[i][4 * j + 1] = v.y; af[i][4 * j + 2] = v.z; af[i][4 * j + 3] = v.w;
+                tapmask[i] |= (tok || !ok || tap >= 9) ? (1u << j) : 0u;
             }
         } else {
             const float* src = ok ? x + (((size_t)b * H + hi) * W + wi) * CIN + lh * KH2 : x;
 #pragma unroll
             for (int k = 0; k < KH2; k += 4) {
                 const float4 v = *reinterpret_cast<const float4*>(src + k);
-                af[i][k] = ok ? v.x : 0.f; af[i][k + 1] = ok ? v.y : 0.f; af[i][k + 2] = ok ? v.z : 0.f; af[i][k + 3] = ok ? v.w : 0.f;
+                af[i][k] = v.x; af[i][k + 1] = v.y; af[i][k + 2] = v.z; af[i][k + 3] = v.w;
             }
         }
         // bit r set: row r needs no zeroing (rows past the tile's last pixel are never read by the depthwise phase);
@@ -102,58 +108,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     const int q = tid & 7, sidx = tid >> 3;
     const size_t ybase = (size_t)b * Ho * Wo;
 
-    // Per-chunk parameters are fetched one chunk ahead so that no phase waits for a global load it has just issued.
-    float bf[KH2], sc, bi;
+    // Per-chunk parameters are fetched one chunk ahead so that no phase waits for a global load it has just issued; the
+    // fetched values are consumed (scaled, stored to LDS) only when the chunk that fetched them hands over.
+    // B fragment, raw: fold_b() multiplies the folded-BN scale into it (a lane's B values all belong to its one output
+    // channel); the bias seeds the accumulator, so the MFMA chain ends with the normalised value.
+    float bf[KH2], bi;
     auto load_expand_params = [&](int ch, float (&f)[KH2], float& s_, float& b_) {
         const int cn = ch * XD_CC + lr;
         const bool cok = cn < Cexp;
         constexpr int WLD = STEM ? 36 : CIN;      // floats per weight row in memory
         const float* wsrc = we + (size_t)(cok ? cn : 0) * WLD + lh * KH2;
-        s_ = cok ? (es ? es[cn] : 1.f) : 0.f;
-        b_ = cok ? (eb ? eb[cn] : 0.f) : 0.f;
-        // the folded-BN scale goes into the weights (a lane's B values all belong to its one output channel) and the
-        // bias into the initial accumulator, so the MFMA chain ends with the normalised value
+        s_ = (cok && es) ? es[cn] : (cok ? 1.f : 0.f);
+        b_ = (cok && eb) ? eb[cn] : 0.f;
 #pragma unroll
         for (int k = 0; k < KH2; k += 4) {
             const bool kok = !STEM || lh * KH2 + k < 36;
             const float4 v = *reinterpret_cast<const float4*>(kok ? wsrc + k : we);
-            f[k] = kok ? v.x * s_ : 0.f; f[k + 1] = kok ? v.y * s_ : 0.f; f[k + 2] = kok ? v.z * s_ : 0.f; f[k + 3] = kok ? v.w * s_ : 0.f;
+            f[k] = v.x; f[k + 1] = v.y; f[k + 2] = v.z; f[k + 3] = v.w;
         }
     };
-    // thread t < WROWS*8 owns float4 (row t/8, quad t%8) of the chunk's depthwise parameter block
+    auto fold_b = [&](float (&dst)[KH2], const float (&f)[KH2], float s_) {
+#pragma unroll
+        for (int k = 0; k < KH2; ++k) dst[k] = (!STEM || lh * KH2 + (k & ~3) < 36) ? f[k] * s_ : 0.f;
+    };
+    // thread t < WROWS*8 owns float4 (row t/8, quad t%8) of the chunk's depthwise parameter block: a weight row (to be
+    // multiplied by the folded-BN scale, fold_dw) or the bias row
     const int wrow = tid >> 3;
-    auto load_dw_params = [&](int ch) -> float4 {
+    auto load_dw_params = [&](int ch, float4& v, float4& s4) {
         const int c = ch * XD_CC + q * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        s4 = make_float4(1.f, 1.f, 1.f, 1.f);
         if (wrow < WROWS && c < Cexp) {
             if (wrow < KS * KS) {
                 v = *reinterpret_cast<const float4*>(wd + (size_t)wrow * Cexp + c);
-                if (dsc) {
-                    const float4 s4 = *reinterpret_cast<const float4*>(dsc + c);
-                    v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
-                }
+                if (dsc) s4 = *reinterpret_cast<const float4*>(dsc + c);
             } else if (dbi) {
                 v = *reinterpret_cast<const float4*>(dbi + c);
             }
         }
-        return v;
     };
+    auto fold_dw = [&](const float4& v, const float4& s4) { return make_float4(v.x * s4.x, v.y * s4.y, v.z * s4.z, v.w * s4.w); };
     const int ch_begin = blockIdx.z * cpg;
-    load_expand_params(ch_begin, bf, sc, bi);
-    if (wrow < WROWS) Wl[ch_begin & 1][wrow][q] = load_dw_params(ch_begin);
+    {
+        float braw[KH2], s_;
+        load_expand_params(ch_begin, braw, s_, bi);
+        float4 wv, ws4;
+        load_dw_params(ch_begin, wv, ws4);
+        fold_b(bf, braw, s_);
+        if (wrow < WROWS) Wl[ch_begin & 1][wrow][q] = fold_dw(wv, ws4);
+    }
 
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int c0 = ch * XD_CC;
         const int chn = ch + 1 < ch_end ? ch + 1 : ch;
         float bfn[KH2], scn, bin;
         load_expand_params(chn, bfn, scn, bin);
-        const float4 wln = load_dw_params(chn);
+        float4 wln, wsn;
+        load_dw_params(chn, wln, wsn);
         // ---- expand: E = swish(bn(A W^T)) for 32 channels ----
         {
 #pragma unroll
             for (int i = 0; i < NRB; ++i) {
                 const int rb = wave + 4 * i;
                 if (rb < MB) {
+                    if constexpr (STEM) {
+                        if (__any(tapmask[i] != 0x1f)) {
+#pragma unroll
+                            for (int j = 0; j < 5; ++j)
+                                if (!((tapmask[i] >> j) & 1u)) { af[i][4 * j] = 0.f; af[i][4 * j + 1] = 0.f; af[i][4 * j + 2] = 0.f; af[i][4 * j + 3] = 0.f; }
+                        }
+                    }
                     f32x16 acc;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[e] = bi;
@@ -183,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
                 }
             }
         }
-        if (wrow < WROWS) Wl[(ch + 1) & 1][wrow][q] = wln;
+        if (wrow < WROWS) Wl[(ch + 1) & 1][wrow][q] = fold_dw(wln, wsn);
         __syncthreads();
 
         // ---- depthwise over E ----
@@ -251,9 +275,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
             for (int w2 = 1; w2 < 4; ++w2) { t.x += red[w2][tid].x; t.y += red[w2][tid].y; t.z += red[w2][tid].z; t.w += red[w2][tid].w; }
             *reinterpret_cast<float4*>(partial + ((size_t)b * gridDim.x + tile) * Cexp + c) = t;
         }
-#pragma unroll
-        for (int k = 0; k < KH2; ++k) bf[k] = bfn[k];
-        sc = scn; bi = bin;
+        fold_b(bf, bfn, scn);
+        bi = bin;
     }
 }
 

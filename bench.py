@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("caption", "train"), default="caption")
-    ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 256 captioning, 64 training)")
+    ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 1024 captioning, 64 training)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=384, help="images in the CPU-baseline sample")
@@ -119,7 +119,7 @@ def main():
     from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images
 
     train = args.mode == "train"
-    B = args.batch or (64 if train else 256)
+    B = args.batch or (64 if train else 1024)
     # synthetic images: a small seeded pool tiled to the batch (content does not change the work)
     pool = synthetic_images(min(B, 32), seed=1234 + rank)
     images = pool.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1, 1, 1)[:B].contiguous().to(dev)

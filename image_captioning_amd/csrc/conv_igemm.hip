@@ -48,6 +48,19 @@ struct ConvParams {
     int* amax_idx;          // their column indices
 };
 
+// Phase time stamps for the tuning probe under tools/ (compiled in only there): wave 0 of the first 64 workgroups,
+// K steps 0..31 of their first tile, four stamps per step.
+#ifdef ICAP_IGEMM_PROF
+__device__ unsigned long long g_igemm_prof[64 * 32 * 4];
+#define IG_STAMP(t, k)                                                                                       \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < 64 && (t) < 32 && tl == (int)blockIdx.x)                        \
+            g_igemm_prof[(blockIdx.x * 32 + (t)) * 4 + (k)] = __builtin_amdgcn_s_memtime();                  \
+    } while (0)
+#else
+#define IG_STAMP(t, k)
+#endif
+
 constexpr int BK = 16;       // K elements one wave consumes per step
 constexpr int EP_ROWS = 64;  // output rows per epilogue pass
 
@@ -65,7 +78,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // PF: K slices in flight in registers (the number of K steps must be a multiple of it).  A
 // workgroup that is alone on its CU - few-tile problems such as the decoder GEMMs at 256 rows -
 // otherwise stalls every step for the part of the memory latency one step of MFMAs does not cover.
-template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC, int PF = 1, bool AMAX = false>
+template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC, int PF = 1, bool AMAX = false, bool FRAG = false>
 __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = 64 * WM * WN * KSPLIT;   // threads: one wave per (row block, column block, K split)
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -149,7 +162,8 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
     // consumes a loaded value before lds_store(), so the loads of the next slice - or of the next
     // tile's first slice - stay in flight behind the MFMAs and the epilogue instead of being waited
     // for where they are issued.
-    constexpr int NSET = PF;
+    constexpr int NSET = FRAG ? 2 : PF;
+    static_assert(!FRAG || PF == 1, "the fragment pipeline has its own two-slice prefetch");
     float4 ra[NSET][RA], rb[NSET][RB], rg[NSET][GATE ? RA : 1];
     unsigned okmask_s[NSET];   // bit i: ra[i] valid, bit 16+i: rb[i] valid
 
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
     if (tl >= p.nblk) return;
     setup_tile(tl);
     gload(0, SetTag<0>{});
-    static_for<1, PF>([&](auto st) { gload(decltype(st)::value, st); });
+    static_for<1, NSET>([&](auto st) { gload(decltype(st)::value, st); });
 
     float* ep = smem;  // [KSPLIT][EP_R][EP_LD]; aliases the staging buffers, used only between K loops
     constexpr int BN4 = BN / 4;
@@ -217,9 +231,11 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
     const int en4 = tid % BN4, erow = tid / BN4;
 
     while (true) {
-        // registers hold K slices 0..PF-1 of tile tl, staging coordinates describe tile tl
-        lds_store(0, SetTag<0>{});
-        __syncthreads();
+        // registers hold K slices 0..NSET-1 of tile tl, staging coordinates describe tile tl
+        if constexpr (!FRAG) {
+            lds_store(0, SetTag<0>{});
+            __syncthreads();
+        }
         const int em0 = m0, en0 = n0;
         const int next = tl + G;
         const bool has_next = next < p.nblk;
@@ -267,7 +283,99 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
             }
         };
 
-        if constexpr (PF > 1) {
+        if constexpr (FRAG) {
+            // Fragment pipeline: the MFMA operands of step t+1 are read from LDS into a second register set while
+            // the MFMAs of step t run from the first, so a step is [issue LDS reads] [MFMAs back to back] [move slice
+            // t+2 from its staging registers to the LDS buffer slice t's fragments came from] [fetch slice t+4 into
+            // those staging registers] [barrier]: no MFMA waits for an LDS read issued in its own step, and a fetched
+            // slice has two steps to arrive.  Needs an even number (>= 4) of K steps; the steady-state loop is
+            // branch-free, the last four steps are peeled and fetch the next tile's slices 0 and 1.
+            float fa[2][KU][RM][8], fb[2][KU][RN][8];
+            auto read_frags = [&](auto buf_tag, auto par_tag) {
+                constexpr int BUF = decltype(buf_tag)::value, PAR = decltype(par_tag)::value;
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    const int koff = (ks * KU + u) * BK + 8 * lh;
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) {
+                        const float* src = &As[(BUF * BM + wm * TM + i * 32 + lr) * LDK + koff];
+                        const float4 v0 = *reinterpret_cast<const float4*>(src);
+                        const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+                        fa[PAR][u][i][0] = v0.x; fa[PAR][u][i][1] = v0.y; fa[PAR][u][i][2] = v0.z; fa[PAR][u][i][3] = v0.w;
+                        fa[PAR][u][i][4] = v1.x; fa[PAR][u][i][5] = v1.y; fa[PAR][u][i][6] = v1.z; fa[PAR][u][i][7] = v1.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) {
+                        const float* src = &Bs[(BUF * BN + wn * TN + j * 32 + lr) * LDK + koff];
+                        const float4 v0 = *reinterpret_cast<const float4*>(src);
+                        const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+                        fb[PAR][u][j][0] = v0.x; fb[PAR][u][j][1] = v0.y; fb[PAR][u][j][2] = v0.z; fb[PAR][u][j][3] = v0.w;
+                        fb[PAR][u][j][4] = v1.x; fb[PAR][u][j][5] = v1.y; fb[PAR][u][j][6] = v1.z; fb[PAR][u][j][7] = v1.w;
+                    }
+                }
+            };
+            auto mma = [&](auto par_tag) {
+                constexpr int PAR = decltype(par_tag)::value;
+#pragma unroll
+                for (int u = 0; u < KU; ++u)
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)
+#pragma unroll
+                        for (int i = 0; i < RM; ++i)
+#pragma unroll
+                            for (int j = 0; j < RN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[PAR][u][i][s], fb[PAR][u][j][s], acc[i][j], 0, 0, 0);
+            };
+            using T0 = SetTag<0>;
+            using T1 = SetTag<1>;
+            // staging sets 0 / 1 hold slices 0 / 1 (fetched during the previous tile's last steps and epilogue)
+            lds_store(0, T0{});
+            gload(2, T0{});
+            __syncthreads();
+            read_frags(T0{}, T0{});
+            lds_store(1, T1{});
+            gload(3, T1{});
+            __syncthreads();
+            // step t (even): fragments(t) in set 0, LDS buffer 1 = slice t+1, staging 0 / 1 = slices t+2 / t+3
+            for (int t = 0; t + 6 <= nk; t += 2) {
+                IG_STAMP(t, 0);
+                read_frags(T1{}, T1{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma(T0{});
+                __builtin_amdgcn_sched_barrier(0);
+                IG_STAMP(t, 1);
+                lds_store(0, T0{});
+                gload(t + 4, T0{});
+                IG_STAMP(t, 2);
+                __syncthreads();
+                IG_STAMP(t, 3);
+                read_frags(T0{}, T0{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma(T1{});
+                __builtin_amdgcn_sched_barrier(0);
+                lds_store(1, T1{});
+                gload(t + 5, T1{});
+                __syncthreads();
+            }
+            read_frags(T1{}, T1{});                 // step nk-4
+            mma(T0{});
+            lds_store(0, T0{});
+            if (has_next) {
+                setup_tile(next);
+                gload(0, T0{});
+            }
+            __syncthreads();
+            read_frags(T0{}, T0{});                 // step nk-3
+            mma(T1{});
+            lds_store(1, T1{});
+            if (has_next) gload(1, T1{});
+            __syncthreads();
+            read_frags(T1{}, T1{});                 // step nk-2
+            mma(T0{});
+            __syncthreads();
+            mma(T1{});                              // step nk-1
+            __syncthreads();
+        } else if constexpr (PF > 1) {
             // Step t fetches slice t+PF into the register set slice t came from, multiplies slice t, then
             // moves slice t+1 (fetched PF-1 steps earlier) into the other LDS buffer.  The steady-state
             // loop body is branch-free so that the compiler's wait counts let the newer fetches stay in
@@ -301,6 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
         } else {
             for (int t = 0; t < nk; ++t) {
                 const bool more = (t + 1) < nk;
+                IG_STAMP(t, 0);
                 if (more) {
                     gload(t + 1, SetTag<0>{});
                 } else if (has_next) {   // prefetch the next tile's first slice; it lands during the epilogue
@@ -308,8 +417,11 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
                     gload(0, SetTag<0>{});
                 }
                 compute();
+                IG_STAMP(t, 1);
                 if (more) lds_store(cur ^ 1, SetTag<0>{});
+                IG_STAMP(t, 2);
                 __syncthreads();
+                IG_STAMP(t, 3);
                 cur ^= 1;
             }
         }
@@ -438,8 +550,12 @@ static int persistent_grid(K kernel, int nblk, int& cached, int threads) {
 
 // AMAX: the epilogue also emits per-tile row maxima (its own kernel instantiation, so that profiles show the
 // vocabulary projection of greedy decoding under its own name).
-template <int BM, int BN, int WM, int WN, int KSPLIT, int KU = 1, bool VEC = true, int PF = 1, bool AMAX = false>
+template <int BM, int BN, int WM, int WN, int KSPLIT, int KU = 1, bool VEC = true, int PF = 1, bool AMAX = false, bool FRAG = false>
 static int launch_cfg(ConvParams& p, hipStream_t st) {
+    if (FRAG) {
+        const int nk_ = (p.K + BK * KSPLIT * KU - 1) / (BK * KSPLIT * KU);
+        if (nk_ < 4 || (nk_ & 1)) { set_error("conv_igemm: configuration needs an even number (>= 4) of K steps"); return ICAP_ERR_ARG; }
+    }
     if (PF > 1 && (((p.K + BK * KSPLIT * KU - 1) / (BK * KSPLIT * KU)) % PF)) {
         set_error("conv_igemm: this tile configuration needs an even number of K steps");
         return ICAP_ERR_ARG;
@@ -459,7 +575,7 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
 #define ICAP_LAUNCH(O_, G_)                                                                          \
     do {                                                                                             \
         static int cached = 0;                                                                       \
-        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC, PF, AMAX>;                               \
+        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC, PF, AMAX, FRAG>;                               \
         hipLaunchKernelGGL(kern, dim3((unsigned)persistent_grid(kern, p.nblk, cached, (int)block.x)), block, 0, st, p); \
     } while (0)
     if (one && p.gate) ICAP_LAUNCH(true, true);
@@ -508,6 +624,14 @@ static const TileCfg kCfgs[] = {
     {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 1, true, 8>},    // 26: eight
     {128, 64, 1, launch_cfg<128, 64, 2, 2, 1, 1, true, 4>},  // 27
     {32, 32, 4, launch_cfg<32, 32, 1, 1, 4, 1, true, 4>},    // 28
+    // fragment-pipelined K loop (even step counts >= 4 only)
+    {128, 128, 1, launch_cfg<128, 128, 2, 2, 1, 1, true, 1, false, true>},  // 29
+    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 1, true, 1, false, true>},      // 30
+    {128, 64, 1, launch_cfg<128, 64, 2, 2, 1, 1, true, 1, false, true>},    // 31
+    {64, 64, 1, launch_cfg<64, 64, 2, 2, 1, 2, true, 1, false, true>},      // 32
+    {32, 32, 4, launch_cfg<32, 32, 1, 1, 4, 1, true, 1, false, true>},      // 33
+    {256, 64, 1, launch_cfg<256, 64, 4, 1, 1, 1, true, 1, false, true>},    // 34
+    {128, 96, 1, launch_cfg<128, 96, 4, 1, 1, 1, true, 1, false, true>},    // 35
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -659,11 +783,9 @@ int linear_argmax_f32(const float* x, const float* w, const float* scale, const 
     p.amax_val = part_val;
     p.amax_idx = part_idx;
     const int ksteps = (K + BK - 1) / BK;
-    if (const char* e = getenv("ICAP_AMAX_PF")) {
-        const int f = atoi(e);
-        if (f == 8 && ksteps % 8 == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 8, true>(p, st);
-        if (f == 4 && ksteps % 4 == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 4, true>(p, st);
-    }
+    static const int variant = [] { const char* e = getenv("ICAP_AMAX_VARIANT"); return e ? atoi(e) : 0; }();   // tuning experiments only
+    if (variant == 1 && (ksteps & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 2, true>(p, st);
+    if (ksteps >= 4 && (ksteps & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 1, true, true>(p, st);
     if ((ksteps & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 2, true>(p, st);
     return launch_cfg<64, 64, 2, 2, 1, 2, true, 1, true>(p, st);
 }

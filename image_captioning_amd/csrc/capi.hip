@@ -90,6 +90,7 @@ long long image_dot_ws_floats(int, int, int);
 int dwconv_bwd_data_f32(const float*, const float*, int, int, int, int, int, int, int, int, int, int, float*, hipStream_t);
 int dwconv_bwd_weight_f32(const float*, const float*, int, int, int, int, int, int, int, int, int, int, float*, float*, hipStream_t);
 long long dwconv_bwd_weight_ws_floats(int, int, int, int, int);
+int transpose_f32(const float*, int, int, int, float*, hipStream_t);
 int im2col_f32(const float*, int, int, int, int, int, int, int, int, int, int, int, float*, hipStream_t);
 
 static inline long long align4(long long n) { return (n + 3) & ~3LL; }
@@ -522,6 +523,10 @@ int icap_dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, in
     return dwconv_bwd_weight_f32(dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, dw, ws, (hipStream_t)stream);
 }
 long long icap_dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K) { return dwconv_bwd_weight_ws_floats(B, Ho, Wo, C, K); }
+
+int icap_transpose_f32(const float* src, int rows, int cols, int ld_src, float* dst, void* stream) {
+    return transpose_f32(src, rows, cols, ld_src, dst, (hipStream_t)stream);
+}
 
 int icap_im2col_f32(const float* x, int B, int H, int W, int C, int KH, int KW, int S, int pad_t, int pad_l, int Ho, int Wo, float* col,
                     void* stream) {

@@ -162,90 +162,140 @@ int dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, in
 
 // ---------------------------------------------------------------- depthwise convolution, weight gradient
 // dw[r*K+q][c] = sum over (b,ho,wo) of dy[b,ho,wo,c] * x[b, ho*S - pad_t + r, wo*S - pad_l + q, c].
-// TX threads span 4*TX adjacent channels (one float4 each, K*K float4 accumulators), 256/TX threads share a chunk
-// of output pixels; partials [chunk][K*K][C] are added in order by dwconv_wgrad_finish_kernel.
-template <int KK, int TX>
+// A workgroup owns one filter row r (grid.z); a thread owns a channel quad (K float4 accumulators) and walks strips of SW
+// adjacent output pixels of one output row: the strip's dy values and the input row segment under the strip are loaded
+// once and feed all K taps of all SW outputs ((SW-1)*S+K + SW loads instead of SW*(K+1)).  Every load is unconditional
+// from a clamped address (zeroed by a select), so a strip's loads are all in flight before the first is consumed, and
+// the small register footprint (~80) keeps enough waves resident to hide their latency.
+// TX threads span 4*TX adjacent channels, 256/TX threads share a chunk of strips; partials [chunk][K*K][C] are added in
+// order by dwconv_wgrad_finish_kernel.
+template <int K, int S, int SW, int TX>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B,
-                                                                int H, int W, int C, int K, int S, int pad_t, int pad_l, int Ho,
-                                                                int Wo, int rows_per_chunk, float* __restrict__ part) {
-    constexpr int TY = 256 / TX;
+                                                                int H, int W, int C, int pad_t, int pad_l, int Ho, int Wo,
+                                                                int strips_w, int nstrips, int strips_per_chunk,
+                                                                float* __restrict__ part) {
+    constexpr int KK = K * K, TY = 256 / TX, NIN = (SW - 1) * S + K;
     __shared__ float4 red[TY][TX];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int c = (blockIdx.x * TX + tx) * 4;
     const int chunk = blockIdx.y;
-    const long long M = (long long)B * Ho * Wo;
-    const long long lo = (long long)chunk * rows_per_chunk, hi = min(M, lo + rows_per_chunk);
-    float4 acc[KK];
+    const int r = blockIdx.z;              // filter row of this workgroup: K accumulators per thread instead of K*K
+    const int lo = chunk * strips_per_chunk, hi = min(nstrips, lo + strips_per_chunk);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[K];
 #pragma unroll
-    for (int t = 0; t < KK; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < K; ++q) acc[q] = z4;
     if (c < C) {
-        for (long long m = lo + ty; m < hi; m += TY) {
-            const int wo = (int)(m % Wo);
-            const long long t2 = m / Wo;
-            const int ho = (int)(t2 % Ho);
-            const int b = (int)(t2 / Ho);
-            const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)m * C + c);
+#pragma unroll 2
+        for (int sidx = lo + ty; sidx < hi; sidx += TY) {
+            const int sw = sidx % strips_w;
+            const int t2 = sidx / strips_w;
+            const int ho = t2 % Ho;
+            const int b = t2 / Ho;
+            const int wo0 = sw * SW;
+            const int hh = ho * S - pad_t + r, wi0 = wo0 * S - pad_l;
+            if ((unsigned)hh >= (unsigned)H) continue;       // this filter row falls into the padding (image borders only)
+            const float* dyr = dy + (((size_t)b * Ho + ho) * Wo + wo0) * C + c;
+            const float* xr = x + ((size_t)b * H + hh) * W * C + c;
+            float4 d[SW], v[NIN];
 #pragma unroll
-            for (int t = 0; t < KK; ++t) {
-                const int r = t / K, q = t - r * K;
-                const int hi2 = ho * S - pad_t + r, wi2 = wo * S - pad_l + q;
-                if ((unsigned)hi2 < (unsigned)H && (unsigned)wi2 < (unsigned)W) {
-                    const float4 xv = *reinterpret_cast<const float4*>(x + (((size_t)b * H + hi2) * W + wi2) * C + c);
-                    acc[t].x = fmaf(d.x, xv.x, acc[t].x); acc[t].y = fmaf(d.y, xv.y, acc[t].y);
-                    acc[t].z = fmaf(d.z, xv.z, acc[t].z); acc[t].w = fmaf(d.w, xv.w, acc[t].w);
-                }
+            for (int o = 0; o < SW; ++o) {
+                const bool ok = wo0 + o < Wo;
+                d[o] = *reinterpret_cast<const float4*>(ok ? dyr + (size_t)o * C : dyr);      // always a valid address
+                if (!ok) d[o] = z4;
             }
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                const int wi = wi0 + j;
+                const bool ok = (unsigned)wi < (unsigned)W;
+                v[j] = *reinterpret_cast<const float4*>(ok ? xr + (size_t)wi * C : xr);
+                if (!ok) v[j] = z4;
+            }
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+#pragma unroll
+                for (int o = 0; o < SW; ++o) {
+                    const float4 xv = v[o * S + q];
+                    acc[q].x = fmaf(d[o].x, xv.x, acc[q].x); acc[q].y = fmaf(d[o].y, xv.y, acc[q].y);
+                    acc[q].z = fmaf(d[o].z, xv.z, acc[q].z); acc[q].w = fmaf(d[o].w, xv.w, acc[q].w);
+                }
         }
     }
-    for (int t = 0; t < KK; ++t) {
-        red[ty][tx] = acc[t];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        red[ty][tx] = acc[q];
         __syncthreads();
         if (ty == 0 && c < C) {
             float4 s = red[0][tx];
+#pragma unroll 1
             for (int k = 1; k < TY; ++k) { const float4 o = red[k][tx]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
-            *reinterpret_cast<float4*>(part + ((size_t)chunk * KK + t) * C + c) = s;
+            *reinterpret_cast<float4*>(part + ((size_t)chunk * KK + r * K + q) * C + c) = s;
         }
         __syncthreads();
     }
 }
 
-// 64 outputs per workgroup, four lanes per output each adding every fourth chunk (fixed order)
+// 8 outputs per workgroup, 32 lanes per output each adding every 32nd chunk with sixteen loads in flight (fixed order)
 __global__ __launch_bounds__(256) void dwconv_wgrad_finish_kernel(const float* __restrict__ part, int nchunks, int n,
                                                                   float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ky = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + cx;
+    __shared__ float red[32][8];
+    const int cx = threadIdx.x & 7, ky = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + cx;
     float s = 0.f;
-    if (i < n)
-        for (int k = ky; k < nchunks; k += 4) s += part[(size_t)k * n + i];
+    if (i < n) {
+        for (int k0 = ky; k0 < nchunks; k0 += 32 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 32 * u;
+                v[u] = k < nchunks ? part[(size_t)k * n + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+    }
     red[ky][cx] = s;
     __syncthreads();
-    if (ky == 0 && i < n) out[i] = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
+    if (ky == 0 && i < n) {
+        float t = red[0][cx];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) t += red[k][cx];
+        out[i] = t;
+    }
 }
 
-static int dww_rows(long long M, int C) {
+constexpr int DWW_SW = 4;   // strip width: 4 keeps a filter row's loads + K*K accumulators within ~128 registers
+
+// strips per chunk: about 512 chunks (times K filter rows) in all, at least 8 strips per thread row
+static int dww_strips_per_chunk(long long nstrips, int C) {
     const int col_blocks = (C + 255) / 256;
     long long want = 512 / col_blocks;
     if (want < 1) want = 1;
-    long long rows = (M + want - 1) / want;
-    if (rows < 32) rows = 32;
-    return (int)rows;
+    long long per = (nstrips + want - 1) / want;
+    if (per < 8) per = 8;
+    return (int)per;
+}
+
+static long long dww_nstrips(int B, int Ho, int Wo, int K, int S) {
+    const int sw = DWW_SW;
+    (void)K; (void)S;
+    return (long long)B * Ho * ((Wo + sw - 1) / sw);
 }
 
 long long dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K) {
-    const long long M = (long long)B * Ho * Wo;
-    const int rows = dww_rows(M, C);
-    return ((M + rows - 1) / rows) * (long long)K * K * C;
+    const long long ns = dww_nstrips(B, Ho, Wo, K, 1);
+    const int per = dww_strips_per_chunk(ns, C);
+    return ((ns + per - 1) / per) * (long long)K * K * C;
 }
 
-template <int KK>
-static void dww_launch(int tx, dim3 grid, hipStream_t st, const float* dy, const float* x, int B, int H, int W, int C, int K, int S,
-                       int pad_t, int pad_l, int Ho, int Wo, int rows, float* ws) {
+template <int K, int S, int SW>
+static void dww_launch(int tx, dim3 grid, hipStream_t st, const float* dy, const float* x, int B, int H, int W, int C, int pad_t,
+                       int pad_l, int Ho, int Wo, int strips_w, int nstrips, int per, float* ws) {
     switch (tx) {
-        case 8: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KK, 8>), grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws); break;
-        case 16: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KK, 16>), grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws); break;
-        case 32: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KK, 32>), grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws); break;
-        default: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<KK, 64>), grid, dim3(256), 0, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws); break;
+        case 8: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 8>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws); break;
+        case 16: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 16>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws); break;
+        case 32: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 32>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws); break;
+        default: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 64>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws); break;
     }
 }
 
@@ -255,18 +305,22 @@ int dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, int W, 
         set_error("dwconv_bwd_weight: bad arguments");
         return ICAP_ERR_ARG;
     }
-    if (K != 3 && K != 5) { set_error("dwconv_bwd_weight: kernel size %d not supported (3 or 5)", K); return ICAP_ERR_ARG; }
+    if ((K != 3 && K != 5) || (S != 1 && S != 2)) { set_error("dwconv_bwd_weight: kernel %d stride %d not supported (3 or 5, stride 1 or 2)", K, S); return ICAP_ERR_ARG; }
     if (C % 4 || !aligned16(dy) || !aligned16(x) || !aligned16(ws)) { set_error("dwconv_bwd_weight: C %% 4 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
-    const long long M = (long long)B * Ho * Wo;
-    const int rows = dww_rows(M, C);
-    const int nchunks = (int)((M + rows - 1) / rows);
+    const long long ns = dww_nstrips(B, Ho, Wo, K, S);
+    if (ns > 0x7fffffffLL) { set_error("dwconv_bwd_weight: problem too large"); return ICAP_ERR_LIMIT; }
+    const int nstrips = (int)ns;
+    const int per = dww_strips_per_chunk(ns, C);
+    const int nchunks = (nstrips + per - 1) / per;
     const int c4 = C / 4;
     const int tx = c4 <= 8 ? 8 : (c4 <= 16 ? 16 : (c4 <= 32 ? 32 : 64));
-    const dim3 grid((c4 + tx - 1) / tx, nchunks);
-    if (K == 3) dww_launch<9>(tx, grid, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws);
-    else dww_launch<25>(tx, grid, st, dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, rows, ws);
+    const dim3 grid((c4 + tx - 1) / tx, nchunks, K);
+    if (K == 3 && S == 1) dww_launch<3, 1, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws);
+    else if (K == 3) dww_launch<3, 2, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws);
+    else if (S == 1) dww_launch<5, 1, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws);
+    else dww_launch<5, 2, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws);
     const int n = K * K * C;
-    hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3((n + 63) / 64), dim3(256), 0, st, ws, nchunks, n, dw);
+    hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3((n + 7) / 8), dim3(256), 0, st, ws, nchunks, n, dw);
     return launch_status("dwconv_bwd_weight");
 }
 
@@ -301,6 +355,34 @@ int im2col_f32(const float* x, int B, int H, int W, int C, int KH, int KW, int S
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, B, H, W, C, KH, KW, S, pad_t, pad_l, Ho, Wo, col);
     return launch_status("im2col");
+}
+
+// ---------------------------------------------------------------- matrix transpose
+// dst[c][r] = src[r][c] through a 32 x 33 LDS tile (reads and writes both run along rows).  The input-gradient GEMM
+// dX = dY W wants W with the contraction axis contiguous to run on the implicit-GEMM kernel: weights are at most a few
+// MB, so a per-step transposed copy costs microseconds.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int rows, int cols, int lds_, float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[(size_t)r * lds_ + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+int transpose_f32(const float* src, int rows, int cols, int ld_src, float* dst, hipStream_t st) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || ld_src < cols) { set_error("transpose: bad arguments"); return ICAP_ERR_ARG; }
+    if ((cols + 31) / 32 > 65535 || (rows + 31) / 32 > 65535) { set_error("transpose: matrix too large"); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, src, rows, cols, ld_src, dst);
+    return launch_status("transpose");
 }
 
 }  // namespace icap

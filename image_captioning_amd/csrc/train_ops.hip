@@ -137,23 +137,37 @@ __global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __res
 }
 
 // out1[c] = scale * sum_chunks part[chunk][c] (+ out1[c] when accumulate); same for the second plane.
-// 64 columns per workgroup; four lanes per column each add every fourth chunk and meet in LDS, so the chain of
-// dependent loads is a quarter as long and the order of additions is still fixed.
+// 8 columns per workgroup, 32 lanes per column: lane ky adds chunks ky, ky + 32, ... - sixteen independent loads in
+// flight at a time, so a 512-chunk column costs two memory round trips instead of a chain of 128 - and the 32 lanes
+// meet in LDS; the order of additions is fixed.
 __global__ __launch_bounds__(256) void col_finish_kernel(const float* __restrict__ part, int nchunks, int C, int planes,
                                                          float scale, int accumulate, float* __restrict__ out1,
                                                          float* __restrict__ out2) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ky = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ float red[32][8];
+    const int cx = threadIdx.x & 7, ky = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cx;
     for (int pl = 0; pl < planes; ++pl) {
         float s = 0.f;
-        if (c < C)
-            for (int k = ky; k < nchunks; k += 4) s += part[(size_t)(pl * nchunks + k) * C + c];
+        if (c < C) {
+            const float* src = part + (size_t)pl * nchunks * C + c;
+            for (int k0 = ky; k0 < nchunks; k0 += 32 * 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = k0 + 32 * u;
+                    v[u] = k < nchunks ? src[(size_t)k * C] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += v[u];
+            }
+        }
         red[ky][cx] = s;
         __syncthreads();
         if (ky == 0 && c < C) {
+            float t = red[0][cx];
+#pragma unroll
+            for (int k = 1; k < 32; ++k) t += red[k][cx];
             float* o = pl == 0 ? out1 : out2;
-            const float t = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
             o[c] = (accumulate ? o[c] : 0.f) + t * scale;
         }
         __syncthreads();
@@ -220,7 +234,7 @@ int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, c
             default: hipLaunchKernelGGL(col_partial_kernel<COL_LN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
         }
     }
-    hipLaunchKernelGGL(col_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, st, ws, nchunks, C, mode >= COL_BN_BWD ? 2 : 1, scale, accumulate, out1, out2);
+    hipLaunchKernelGGL(col_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, st, ws, nchunks, C, mode >= COL_BN_BWD ? 2 : 1, scale, accumulate, out1, out2);
     return launch_status("col_reduce");
 }
 

@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _native as N
+from . import ops
 from .ops import ACT_NONE, _Span, _ck, _stream
 
 COL_SUM, COL_SQDEV, COL_BN_BWD, COL_LN_BWD = 0, 1, 2, 3
@@ -30,6 +31,15 @@ def _ws(n: int, dev) -> torch.Tensor | None:
     return torch.empty(max(int(n), 1), device=dev, dtype=torch.float32) if n > 0 else None
 
 
+def transpose(a: torch.Tensor) -> torch.Tensor:
+    """[R, C] (rows may be strided) -> dense [C, R]."""
+    _ckr(a, "a")
+    R, C = a.shape
+    out = torch.empty(C, R, device=a.device, dtype=torch.float32)
+    N.check(N.load().icap_transpose_f32(a.data_ptr(), R, C, a.stride(0), out.data_ptr(), _stream()), "transpose")
+    return out
+
+
 def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
     """out[M, N] (+)= a[M, K] @ b[K, N]  (input gradient of a Linear: dX = dY @ W)."""
     _ckr(a, "a"); _ckr(b, "b")
@@ -41,6 +51,11 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, a
         out = torch.empty(M, Nn, device=a.device, dtype=torch.float32)
         accumulate = False
     lib = N.load()
+    if K % 4 == 0 and Nn % 4 == 0 and a.stride(0) == K and out.stride(0) == Nn and M >= 64:
+        # the tuned implicit-GEMM kernel wants the contraction axis of both operands contiguous: a transposed copy of the
+        # (small) second operand buys its 60-100 TFLOP/s instead of the k-major staging of the generic backward kernel
+        bt = transpose(b)
+        return ops.linear(a, bt, residual=out if accumulate else None, out=out)
     ws = _ws(lib.icap_gemm_bwd_ws_floats(M, Nn, K, int(accumulate)), a.device)
     span = _Span("gemm_nn", (M, K, Nn))
     N.check(lib.icap_gemm_bwd_f32(a.data_ptr(), a.stride(0), 0, b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, Nn, K,

@@ -387,6 +387,11 @@ int icap_dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, in
                                int pad_l, int Ho, int Wo, float* dw, float* ws, void* stream);
 long long icap_dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K);
 
+/* dst[c][r] = src[r][c] (src rows `ld_src` floats apart, dst dense [cols][rows]).  Used by the training step to hand a
+ * Linear / 1x1-convolution weight to icap_conv2d_f32 with the contraction axis contiguous for the input gradient
+ * dX = dY W (the backward of every nn.Linear / Conv2d on the path, e.g. transformer_word_level_bahdnau.py:188-196). */
+int icap_transpose_f32(const float* src, int rows, int cols, int ld_src, float* dst, void* stream);
+
 /* col[m][(r*KW+q)*C + c] = x[b, ho*S-pad_t+r, wo*S-pad_l+q, c]: patches of the stem convolution's input, so that
  * its weight gradient is one icap_gemm_bwd_f32 (a_kmajor = 1) call. */
 int icap_im2col_f32(const float* x, int B, int H, int W, int C, int KH, int KW, int S, int pad_t, int pad_l, int Ho,

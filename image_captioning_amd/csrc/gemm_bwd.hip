@@ -156,11 +156,151 @@ static int pick_splits(int M, int N, int K) {
     return (int)(s < 1 ? 1 : s);
 }
 
+// ---------------------------------------------------------------- tall-and-skinny TN form
+// C[M][N] = A^T B with A [K][M], B [K][N], K in the hundreds of thousands to millions and M, N at most a few 32-wide
+// blocks: the weight gradient of the thin 1x1 convolutions at high resolution.  The problem is a streaming reduction
+// over K (both operands are read once, the result is a few KB), so nothing is staged: a wave owns a contiguous range of
+// K rows and the whole MB x NB block tile in MFMA accumulators, and loads its operands straight in the MFMA's layout -
+// lane (r, h) reads A[k + h][m0 + r] (32 lanes = one 128-byte row segment) - U row pairs in flight at a time.  The four
+// waves of a workgroup add their tiles in LDS in wave order, workgroups write partial tiles [chunk][M][N] and
+// gemm_tn_finish_kernel adds the chunks in a fixed order.
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+constexpr int SK_U = 8;          // row pairs in flight per wave
+constexpr int SK_CHUNKS = 512;   // workgroups along K
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                             int ldb, int K, int M, int N, int rows_per_wave,
+                                                             float* __restrict__ part) {
+    __shared__ float tile[MB * 32][NB * 32 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int chunk = blockIdx.x;
+    const int mt = blockIdx.y * MB * 32, nt = blockIdx.z * NB * 32;
+    const int r_lo = (chunk * 4 + wave) * rows_per_wave;
+    const int r_hi = min(K, r_lo + rows_per_wave);
+    f32x16s acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bool a_ok[MB], b_ok[NB];
+    int a_col[MB], b_col[NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) { a_ok[i] = mt + i * 32 + lr < M; a_col[i] = a_ok[i] ? mt + i * 32 + lr : 0; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { b_ok[j] = nt + j * 32 + lr < N; b_col[j] = b_ok[j] ? nt + j * 32 + lr : 0; }
+    for (int r = r_lo; r < r_hi; r += 2 * SK_U) {
+        float av[SK_U][MB], bv[SK_U][NB];
+#pragma unroll
+        for (int u = 0; u < SK_U; ++u) {
+            const int row = r + 2 * u + lh;
+            const bool ok = row < r_hi;
+            const size_t rc = (size_t)(ok ? row : r_lo);          // always a valid row
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                av[u][i] = a[rc * lda + a_col[i]];
+                if (!(ok && a_ok[i])) av[u][i] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                bv[u][j] = b[rc * ldb + b_col[j]];
+                if (!(ok && b_ok[j])) bv[u][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SK_U; ++u)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+    }
+    // the four waves meet in LDS in wave order (a lane holds column lr and rows (e&3) + 8*(e>>2) + 4*lh of a block)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float& t = tile[i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh][j * 32 + lr];
+                        t = (w == 0 ? 0.f : t) + acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+    }
+    float* dst = part + (size_t)chunk * M * N;
+    for (int idx = threadIdx.x; idx < MB * 32 * NB * 32; idx += 256) {
+        const int mi = idx / (NB * 32), ni = idx - mi * (NB * 32);
+        if (mt + mi < M && nt + ni < N) dst[(size_t)(mt + mi) * N + nt + ni] = tile[mi][ni];
+    }
+}
+
+// c[m][n] (+)= sum over chunks of part[chunk][m][n]: 8 outputs per workgroup, 32 lanes per output each adding every 32nd
+// chunk with sixteen loads in flight; fixed order.
+__global__ __launch_bounds__(256) void gemm_tn_finish_kernel(const float* __restrict__ part, int nchunks, int M, int N,
+                                                             float* __restrict__ c, int ldc, int accumulate) {
+    __shared__ float red[32][8];
+    const int cx = threadIdx.x & 7, ky = threadIdx.x >> 3;
+    const int total = M * N;
+    const int i = blockIdx.x * 8 + cx;
+    float s = 0.f;
+    if (i < total) {
+        for (int k0 = ky; k0 < nchunks; k0 += 32 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 32 * u;
+                v[u] = k < nchunks ? part[(size_t)k * total + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+    }
+    red[ky][cx] = s;
+    __syncthreads();
+    if (ky == 0 && i < total) {
+        float t = red[0][cx];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) t += red[k][cx];
+        float* o = c + (size_t)(i / N) * ldc + i % N;
+        *o = (accumulate ? *o : 0.f) + t;
+    }
+}
+
+// The skinny form pays when the contraction is long and the result is at most a few blocks.
+static bool skinny_tn(int M, int N, int K) {
+    return K >= 32768 && (long long)((M + 31) / 32) * ((N + 31) / 32) <= 16 && (long long)M * N <= (1 << 20);
+}
+
+static int skinny_chunks(int K) {
+    int chunks = SK_CHUNKS;
+    while (chunks > 1 && K / (chunks * 4) < 4 * SK_U) chunks >>= 1;    // at least two batches of rows per wave
+    return chunks;
+}
+
+template <int MB, int NB>
+static void skinny_launch(const float* a, int lda, const float* b, int ldb, int K, int M, int N, int chunks, float* ws, hipStream_t st) {
+    int rpw = (K + chunks * 4 - 1) / (chunks * 4);
+    rpw = (rpw + 1) & ~1;                                   // row pairs must not straddle two waves
+    const dim3 grid(chunks, (M + MB * 32 - 1) / (MB * 32), (N + NB * 32 - 1) / (NB * 32));
+    hipLaunchKernelGGL((gemm_tn_skinny_kernel<MB, NB>), grid, dim3(256), 0, st, a, lda, b, ldb, K, M, N, rpw, ws);
+}
+
 // floats of workspace gemm_bwd_f32 needs for this problem (0 when the contraction is not split and the result
-// is not accumulated onto C)
+// is not accumulated onto C); sized for either operand layout
 long long gemm_bwd_ws_floats(int M, int N, int K, int accumulate) {
     const int s = pick_splits(M, N, K);
-    return (s > 1 || accumulate) ? (long long)s * M * N : 0;
+    long long need = (s > 1 || accumulate) ? (long long)s * M * N : 0;
+    if (skinny_tn(M, N, K)) {
+        const long long sk = (long long)skinny_chunks(K) * M * N;
+        if (sk > need) need = sk;
+    }
+    return need;
 }
 
 // C[M][N] (+)= op(A) . B with B stored [K][N]; op(A) = A stored [M][K] (a_kmajor = 0) or A stored [K][M] (1).
@@ -171,6 +311,32 @@ int gemm_bwd_f32(const float* a, int lda, int a_kmajor, const float* b, int ldb,
         return ICAP_ERR_ARG;
     }
     if (!aligned16(a) || !aligned16(b)) { set_error("gemm_bwd: operands must be 16-byte aligned"); return ICAP_ERR_ALIGN; }
+    if (a_kmajor && skinny_tn(M, N, K)) {
+        if (!ws) { set_error("gemm_bwd: workspace required (gemm_bwd_ws_floats)"); return ICAP_ERR_ARG; }
+        const int chunks = skinny_chunks(K);
+        const int mb = (M + 31) / 32, nb = (N + 31) / 32;
+        // one of the two tile extents is a single block; the other covers up to five, the grid tiles the rest
+        if (mb >= nb) {
+            const int t = mb > 5 ? (mb + 1) / 2 > 5 ? 4 : (mb + 1) / 2 : mb;
+            switch (t) {
+                case 1: skinny_launch<1, 1>(a, lda, b, ldb, K, M, N, chunks, ws, st); break;
+                case 2: skinny_launch<2, 1>(a, lda, b, ldb, K, M, N, chunks, ws, st); break;
+                case 3: skinny_launch<3, 1>(a, lda, b, ldb, K, M, N, chunks, ws, st); break;
+                case 4: skinny_launch<4, 1>(a, lda, b, ldb, K, M, N, chunks, ws, st); break;
+                default: skinny_launch<5, 1>(a, lda, b, ldb, K, M, N, chunks, ws, st); break;
+            }
+        } else {
+            const int t = nb > 5 ? (nb + 1) / 2 > 5 ? 4 : (nb + 1) / 2 : nb;
+            switch (t) {
+                case 2: skinny_launch<1, 2>(a, lda, b, ldb, K, M, N, chunks, ws, st); break;
+                case 3: skinny_launch<1, 3>(a, lda, b, ldb, K, M, N, chunks, ws, st); break;
+                case 4: skinny_launch<1, 4>(a, lda, b, ldb, K, M, N, chunks, ws, st); break;
+                default: skinny_launch<1, 5>(a, lda, b, ldb, K, M, N, chunks, ws, st); break;
+            }
+        }
+        hipLaunchKernelGGL(gemm_tn_finish_kernel, dim3((M * N + 7) / 8), dim3(256), 0, st, ws, chunks, M, N, c, ldc, accumulate);
+        return launch_status("gemm_bwd (skinny)");
+    }
     int splits = pick_splits(M, N, K);
     if (splits > 1 && !ws) { set_error("gemm_bwd: workspace required (gemm_bwd_ws_floats)"); return ICAP_ERR_ARG; }
     GemmParams p{a, b, c, M, N, K, lda, ldb, ldc, splits, 0};

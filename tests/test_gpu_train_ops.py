@@ -22,7 +22,8 @@ def test_gemm_nn(M, K, N):
     torch.testing.assert_close(got, a.double().mm(b.double()).float(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("K,M,N", [(240, 6756, 512), (150528, 96, 16), (12, 512, 1024), (3136, 144, 24), (37, 20, 36), (2352, 1152, 192)])
+@pytest.mark.parametrize("K,M,N", [(240, 6756, 512), (150528, 96, 16), (12, 512, 1024), (3136, 144, 24), (37, 20, 36), (2352, 1152, 192),
+                                   (40000, 24, 144), (33001, 36, 32), (50000, 240, 40), (65537, 17, 33), (40000, 144, 144)])
 def test_gemm_tn(K, M, N):
     from image_captioning_amd import train_ops as T
     a, b = rnd(K, M, seed=3), rnd(K, N, seed=4) * K ** -0.5

@@ -5,7 +5,7 @@
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-    python bench.py --mode train [--batch 64]        # the second half of the metric: training imgs/s
+    python bench.py --mode train [--batch 256]        # the second half of the metric: training imgs/s
 
 --mode train times the teacher-forced training step of the Bahdanau captioner (EfficientNet-B0 in train mode,
 encoder block, 20-step LSTMCell decoder, masked cross entropy, backward, AdamW; data-parallel with a bucketed
@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("caption", "train"), default="caption")
-    ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 1024 captioning, 64 training)")
+    ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 1024 captioning, 256 training)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=384, help="images in the CPU-baseline sample")
@@ -119,7 +119,7 @@ def main():
     from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images
 
     train = args.mode == "train"
-    B = args.batch or (64 if train else 1024)
+    B = args.batch or (256 if train else 1024)
     # synthetic images: a small seeded pool tiled to the batch (content does not change the work)
     pool = synthetic_images(min(B, 32), seed=1234 + rank)
     images = pool.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1, 1, 1)[:B].contiguous().to(dev)

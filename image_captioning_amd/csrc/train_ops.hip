@@ -19,6 +19,7 @@ enum ColMode : int {
     COL_SQDEV = 1,      // s1 = sum (a - v1[c])^2                                (variance given the mean)
     COL_BN_BWD = 2,     // s1 = sum g, s2 = sum g * (x - v1[c]) * v2[c]          (g = a * act'(x*v3[c] + v4[c]))
     COL_LN_BWD = 3,     // s1 = sum a, s2 = sum a * (x - r1[r]) * r2[r]          (per-row mean / rstd)
+    COL_MOMENTS = 4,    // s1 = sum (a - v1[c]), s2 = sum (a - v1[c])^2          (mean and variance in one pass, v1 = a shift near the mean)
 };
 
 __device__ __forceinline__ float act_grad(float z, int act) {
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     float s1 = 0.f, s2 = 0.f;
     if (c < C) {
         float m = 0.f, rs = 0.f, sc = 0.f, bi = 0.f;
-        if (MODE == COL_SQDEV || MODE == COL_BN_BWD) m = v1[c];
+        if (MODE == COL_SQDEV || MODE == COL_BN_BWD || MODE == COL_MOMENTS) m = v1[c];
         if (MODE == COL_BN_BWD) { rs = v2[c]; sc = v3[c]; bi = v4[c]; }
         for (int r = r_lo + ry; r < r_hi; r += 4) {
             const float av = a[(size_t)r * lda + c];
@@ -59,6 +60,10 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
                 const float g = av * act_grad(fmaf(xv, sc, bi), act);
                 s1 += g;
                 s2 += g * ((xv - m) * rs);
+            } else if (MODE == COL_MOMENTS) {
+                const float d = av - m;
+                s1 += d;
+                s2 += d * d;
             } else {
                 const float xv = x[(size_t)r * ldx + c];
                 s1 += av;
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __res
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     if (c < C) {
         float4 m = s1, rs = s1, sc = s1, bi = s1;
-        if (MODE == COL_SQDEV || MODE == COL_BN_BWD) m = *reinterpret_cast<const float4*>(v1 + c);
+        if (MODE == COL_SQDEV || MODE == COL_BN_BWD || MODE == COL_MOMENTS) m = *reinterpret_cast<const float4*>(v1 + c);
         if (MODE == COL_BN_BWD) {
             rs = *reinterpret_cast<const float4*>(v2 + c);
             sc = *reinterpret_cast<const float4*>(v3 + c);
@@ -115,6 +120,10 @@ __global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __res
                 s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
                 s2.x += g0 * ((xv.x - m.x) * rs.x); s2.y += g1 * ((xv.y - m.y) * rs.y);
                 s2.z += g2 * ((xv.z - m.z) * rs.z); s2.w += g3 * ((xv.w - m.w) * rs.w);
+            } else if (MODE == COL_MOMENTS) {
+                const float dx = av.x - m.x, dy = av.y - m.y, dz = av.z - m.z, dw = av.w - m.w;
+                s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+                s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
             } else {
                 const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
                 const float mr = r1[r], rr = r2[r];
@@ -205,8 +214,9 @@ static void col_launch_vec(int tx, dim3 grid, hipStream_t st, const float* a, in
 int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, const float* v1, const float* v2,
                    const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C, float scale,
                    int accumulate, float* out1, float* out2, float* ws, hipStream_t st) {
-    if (!a || !out1 || !ws || M <= 0 || C <= 0 || lda < C || mode < 0 || mode > 3) { set_error("col_reduce: bad arguments"); return ICAP_ERR_ARG; }
-    if (mode == COL_SQDEV && !v1) { set_error("col_reduce: mean required"); return ICAP_ERR_ARG; }
+    if (!a || !out1 || !ws || M <= 0 || C <= 0 || lda < C || mode < 0 || mode > 4) { set_error("col_reduce: bad arguments"); return ICAP_ERR_ARG; }
+    if ((mode == COL_SQDEV || mode == COL_MOMENTS) && !v1) { set_error("col_reduce: mean / shift vector required"); return ICAP_ERR_ARG; }
+    if (mode == COL_MOMENTS && !out2) { set_error("col_reduce: two outputs required"); return ICAP_ERR_ARG; }
     if (mode == COL_BN_BWD && (!x || !v1 || !v2 || !v3 || !v4 || !out2 || ldx < C)) { set_error("col_reduce: BatchNorm operands required"); return ICAP_ERR_ARG; }
     if (mode == COL_LN_BWD && (!x || !r1 || !r2 || !out2 || ldx < C)) { set_error("col_reduce: LayerNorm operands required"); return ICAP_ERR_ARG; }
     const bool vec = (C % 4 == 0) && (lda % 4 == 0) && aligned16(a) && (!x || ((ldx % 4 == 0) && aligned16(x))) &&
@@ -222,6 +232,7 @@ int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, c
             case COL_SUM: col_launch_vec<COL_SUM>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
             case COL_SQDEV: col_launch_vec<COL_SQDEV>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
             case COL_BN_BWD: col_launch_vec<COL_BN_BWD>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+            case COL_MOMENTS: col_launch_vec<COL_MOMENTS>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
             default: col_launch_vec<COL_LN_BWD>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
         }
     } else {
@@ -231,6 +242,7 @@ int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, c
             case COL_SUM: hipLaunchKernelGGL(col_partial_kernel<COL_SUM>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
             case COL_SQDEV: hipLaunchKernelGGL(col_partial_kernel<COL_SQDEV>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
             case COL_BN_BWD: hipLaunchKernelGGL(col_partial_kernel<COL_BN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
+            case COL_MOMENTS: hipLaunchKernelGGL(col_partial_kernel<COL_MOMENTS>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
             default: hipLaunchKernelGGL(col_partial_kernel<COL_LN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
         }
     }
@@ -257,6 +269,38 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     b[c] = (beta ? beta[c] : 0.f) - mean[c] * g * r;
     if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
     if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * (M > 1 ? sqdev[c] / (float)(M - 1) : var);
+}
+
+// The same from one-pass shifted moments: s1 = sum (x - shift), s2 = sum (x - shift)^2 over the M rows.
+//   mean = shift + s1 / M,  sum of squared deviations = s2 - s1^2 / M  (the shift - any row of x - keeps the subtraction benign)
+__global__ __launch_bounds__(256) void bn_finalize_moments_kernel(const float* __restrict__ shift, const float* __restrict__ s1,
+                                                                  const float* __restrict__ s2, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps, float momentum, int M,
+                                                                  int C, float* __restrict__ mean, float* __restrict__ rstd,
+                                                                  float* __restrict__ s, float* __restrict__ b,
+                                                                  float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float a1 = s1[c];
+    const float mu = shift[c] + a1 / (float)M;
+    const float sq = fmaxf(s2[c] - a1 * a1 / (float)M, 0.f);
+    const float var = sq / (float)M;
+    const float r = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f;
+    mean[c] = mu;
+    rstd[c] = r;
+    s[c] = g * r;
+    b[c] = (beta ? beta[c] : 0.f) - mu * g * r;
+    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * (M > 1 ? sq / (float)(M - 1) : var);
+}
+
+int bn_finalize_moments_f32(const float* shift, const float* s1, const float* s2, const float* gamma, const float* beta, float eps,
+                            float momentum, int M, int C, float* mean, float* rstd, float* s, float* b, float* run_mean,
+                            float* run_var, hipStream_t st) {
+    if (!shift || !s1 || !s2 || !mean || !rstd || !s || !b || M <= 0 || C <= 0) { set_error("bn_finalize_moments: bad arguments"); return ICAP_ERR_ARG; }
+    hipLaunchKernelGGL(bn_finalize_moments_kernel, dim3((C + 255) / 256), dim3(256), 0, st, shift, s1, s2, gamma, beta, eps, momentum, M, C, mean, rstd, s, b, run_mean, run_var);
+    return launch_status("bn_finalize_moments");
 }
 
 int bn_finalize_f32(const float* mean, const float* sqdev, const float* gamma, const float* beta, float eps, float momentum,

@@ -12,7 +12,7 @@ from . import _native as N
 from . import ops
 from .ops import ACT_NONE, _Span, _ck, _stream
 
-COL_SUM, COL_SQDEV, COL_BN_BWD, COL_LN_BWD = 0, 1, 2, 3
+COL_SUM, COL_SQDEV, COL_BN_BWD, COL_LN_BWD, COL_MOMENTS = 0, 1, 2, 3, 4
 
 
 def _p(t):
@@ -115,12 +115,14 @@ def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NO
     _ckr(x, "x")
     M, C = x.shape
     dev = x.device
-    mean = col_reduce(COL_SUM, x, scale=1.0 / M)[0]
-    sqdev = col_reduce(COL_SQDEV, x, v1=mean)[0]
-    rstd = torch.empty(C, device=dev); s = torch.empty(C, device=dev); b = torch.empty(C, device=dev)
+    # one pass over x: moments about its first row (a sample of every column, so the subtraction stays benign)
+    shift = x[0]
+    s1, s2 = col_reduce(COL_MOMENTS, x, v1=shift)
+    mean = torch.empty(C, device=dev); rstd = torch.empty(C, device=dev); s = torch.empty(C, device=dev); b = torch.empty(C, device=dev)
     lib = N.load()
-    N.check(lib.icap_bn_finalize_f32(mean.data_ptr(), sqdev.data_ptr(), _p(gamma), _p(beta), float(eps), float(momentum), M, C,
-                                     rstd.data_ptr(), s.data_ptr(), b.data_ptr(), _p(run_mean), _p(run_var), _stream()), "bn_finalize")
+    N.check(lib.icap_bn_finalize_moments_f32(shift.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(gamma), _p(beta), float(eps),
+                                             float(momentum), M, C, mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), b.data_ptr(),
+                                             _p(run_mean), _p(run_var), _stream()), "bn_finalize_moments")
     y = scale_bias_act(x, s, b, act=act, res=res)
     return y, (mean, rstd, s, b)
 

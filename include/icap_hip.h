@@ -297,7 +297,7 @@ long long icap_gemm_bwd_ws_floats(int M, int N, int K, int accumulate);
 /* Column reductions over a [M][C] matrix, two passes in a fixed order.  mode 0: out1 = sum a (bias gradients,
  * BatchNorm mean with scale 1/M); 1: out1 = sum (a - v1[c])^2; 2: BatchNorm gradient sums out1 = sum g,
  * out2 = sum g * xhat with g = a * act'(x*v3 + v4), xhat = (x - v1) * v2; 3: LayerNorm parameter gradients
- * out1 = sum a, out2 = sum a * (x - r1[r]) * r2[r].  Results are multiplied by scale and optionally added onto
+ * out1 = sum a, out2 = sum a * (x - r1[r]) * r2[r]; 4: out1 = sum (a - v1[c]), out2 = sum (a - v1[c])^2.  Results are multiplied by scale and optionally added onto
  * out.  ws: icap_col_reduce_ws_floats(M, C) floats.  nn.BatchNorm1d / BatchNorm2d in train mode
  * (transformer_word_level_bahdnau.py:64,123 and the EfficientNet blocks) and nn.LayerNorm (:57-58). */
 int icap_col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, const float* v1, const float* v2,
@@ -310,6 +310,13 @@ long long icap_col_reduce_ws_floats(int M, int C);
 int icap_bn_finalize_f32(const float* mean, const float* sqdev, const float* gamma, const float* beta, float eps,
                          float momentum, int M, int C, float* rstd, float* s, float* b, float* run_mean,
                          float* run_var, void* stream);
+
+/* The same from ONE pass over x: icap_col_reduce_f32 mode 4 gives s1 = sum (x - shift[c]) and s2 = sum (x - shift[c])^2
+ * (shift: any vector near the column means, e.g. the first row of x); this call turns them into mean (written to
+ * `mean`), rstd, s, b and the running-statistics update. */
+int icap_bn_finalize_moments_f32(const float* shift, const float* s1, const float* s2, const float* gamma, const float* beta,
+                                 float eps, float momentum, int M, int C, float* mean, float* rstd, float* s, float* b,
+                                 float* run_mean, float* run_var, void* stream);
 
 /* y = act(x * s[c] + b[c]) (+ res): normalisation + activation (+ identity skip) over [M][C]. */
 int icap_scale_bias_act_f32(const float* x, int ldx, const float* s, const float* b, const float* res, int ldr, int act,

@@ -256,6 +256,32 @@ class ImageCaptioningModelBase(nn.Module):
                 all_logits.append(logits[:, :wd["out_w"].shape[0]])
         return (ids, torch.stack(all_logits, 0)) if want_logits else ids
 
+    def sample_ids_from_features(self, img_embed, max_len, top_k=10, seed=0):
+        """The reference's actual generation mode (TransformerTest.py:139-164): softmax -> top-k -> one multinomial draw per
+        step, every image its own batch of one, all images in lock-step on the GPU.  Same step structure as the greedy
+        GEMM path; the vocabulary projection writes full logits and the sampling head picks the token (counter-based
+        generator: step t, image r uses element t*B + r of stream `seed`).  top_k = 1 reproduces greedy decoding."""
+        require_eval(self, "ImageCaptioningModel")
+        wd = self._greedy_weights()
+        enc = self.encoder.forward_independent(img_embed)
+        ca = self.decoder.cross_attention_single(enc)                        # [B, E]
+        B = ca.shape[0]
+        V = wd["out_w"].shape[0]
+        start = torch.full((B,), self.start_token, device=ca.device, dtype=torch.int64)
+        ids = torch.empty((B, max_len), device=ca.device, dtype=torch.int64)
+        xin, _ = ops.embedding(wd["emb"], start, add=ca)
+        x = ops.layernorm(xin, wd["ln2_g"], wd["ln2_b"])
+        for t in range(max_len):
+            h = ops.linear(x, wd["fc1_w"], wd["fc1_b"], act=ops.ACT_RELU)
+            f = ops.linear(h, wd["fc2_w"], wd["fc2_b"], residual=x)
+            x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
+            logits = ops.linear(x2, wd["out_w4"], wd["out_b4"])              # vocabulary padded to a multiple of 4 columns
+            ops.topk_sample(logits[:, :V], top_k, seed, t * B, ids_out=ids[:, t], want_topk=False)
+            if t + 1 < max_len:
+                xin, _ = ops.embedding(wd["emb"], ids[:, t].contiguous(), add=ca)
+                x = ops.layernorm(xin, wd["ln2_g"], wd["ln2_b"])
+        return ids
+
     def caption_ids(self, images, max_len=10):
         """Greedy captions (lists of ids, start token dropped, cut before the end token)."""
         feats = self.cnn_model(images)

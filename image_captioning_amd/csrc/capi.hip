@@ -27,6 +27,7 @@ int linear_argmax_parts(int);
 int linear_argmax_f32(const float*, const float*, const float*, const float*, float*, float*, int*, int, int, int, hipStream_t);
 int next_token_f32(const float*, const int*, int, long long*, int, const float*, const float*, const float*, const float*, float,
                    float*, int, int, int, hipStream_t);
+int topk_sample_f32(const float*, int, int, int, int, unsigned long long, unsigned long long, float*, int*, long long*, int, hipStream_t);
 int nchw_to_nhwc_pad_f32(const float*, float*, int, int, int, int, int, hipStream_t);
 int dwconv2d_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
                  int, int, int, int, int, hipStream_t);
@@ -146,6 +147,11 @@ int icap_next_token_f32(const float* part_val, const int* part_idx, int nparts, 
                         int ldo, int rows, int E, void* stream) {
     return next_token_f32(part_val, part_idx, nparts, ids, ids_stride, table, add, gamma, beta, eps, out, ldo, rows, E,
                           (hipStream_t)stream);
+}
+
+int icap_topk_sample_f32(const float* logits, int ld, int rows, int V, int k, unsigned long long seed, unsigned long long offset,
+                         float* probs, int* idx, long long* ids, int ids_stride, void* stream) {
+    return topk_sample_f32(logits, ld, rows, V, k, seed, offset, probs, idx, ids, ids_stride, (hipStream_t)stream);
 }
 
 int icap_dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y, float* partial,

@@ -147,4 +147,13 @@ __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Counter-based uniform in [0, 1): element idx of stream `seed` (a splitmix64 finaliser of seed + idx * golden ratio).
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
 }  // namespace icap

@@ -138,6 +138,94 @@ int argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_stride,
     return launch_status("argmax_rows");
 }
 
+// ---------------------------------------------------------------- top-k sampling head
+// Per row of logits [V]: softmax, the k most probable tokens (probabilities and indices, most probable first, lower
+// index first on ties) and one token drawn among them with probability proportional to its softmax probability -
+// softmax -> topk -> multinomial of the reference's generate_caption - in one workgroup per row.  Every thread keeps its
+// strided share of the row in registers (V <= 256 * TOPK_PER_THREAD); a round finds the workgroup's maximum and retires
+// it.  The draw uses the counter-based generator: row r of call (seed, offset) consumes uniform01(seed, offset + r).
+constexpr int TOPK_PER_THREAD = 32;   // V <= 8192
+constexpr int TOPK_MAX_K = 16;
+
+__global__ __launch_bounds__(256) void topk_sample_kernel(const float* __restrict__ logits, int ld, int V, int k,
+                                                          unsigned long long seed, unsigned long long offset,
+                                                          float* __restrict__ probs, int* __restrict__ idx,
+                                                          long long* __restrict__ ids, int ids_stride) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ float top_p[TOPK_MAX_K];
+    __shared__ int top_i[TOPK_MAX_K];
+    const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* row = logits + (size_t)r * ld;
+    float v[TOPK_PER_THREAD];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < TOPK_PER_THREAD; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = c < V ? row[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) sv[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+    __syncthreads();
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < TOPK_PER_THREAD; ++i) den += (tid + 256 * i < V) ? expf(v[i] - mx) : 0.f;
+    den = wave_sum(den);
+    if (lane == 0) sv[wave] = den;
+    __syncthreads();
+    den = ((sv[0] + sv[1]) + sv[2]) + sv[3];
+    __syncthreads();
+    for (int round = 0; round < k; ++round) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < TOPK_PER_THREAD; ++i) argmax_combine(bv, bi, v[i], tid + 256 * i);
+        wave_argmax(bv, bi);
+        if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+        __syncthreads();
+        bv = sv[0]; bi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, sv[w], si[w]);
+        if (tid == 0) { top_p[round] = expf(bv - mx) / den; top_i[round] = bi; }
+        // retire the winner in its owner's registers
+#pragma unroll
+        for (int i = 0; i < TOPK_PER_THREAD; ++i)
+            if (tid + 256 * i == bi) v[i] = -INFINITY;
+        __syncthreads();
+    }
+    if (tid < k) {
+        if (probs) probs[(size_t)r * k + tid] = top_p[tid];
+        if (idx) idx[(size_t)r * k + tid] = top_i[tid];
+    }
+    if (tid == 0 && ids) {
+        float total = 0.f;
+        for (int j = 0; j < k; ++j) total += top_p[j];
+        const float u = uniform01(seed, offset + (unsigned long long)r) * total;
+        float cum = 0.f;
+        int pick = top_i[k - 1];
+        for (int j = 0; j < k; ++j) {
+            cum += top_p[j];
+            if (u < cum) { pick = top_i[j]; break; }
+        }
+        ids[(size_t)r * ids_stride] = pick;
+    }
+}
+
+int topk_sample_f32(const float* logits, int ld, int rows, int V, int k, unsigned long long seed, unsigned long long offset,
+                    float* probs, int* idx, long long* ids, int ids_stride, hipStream_t st) {
+    if (!logits || rows <= 0 || V <= 0 || ld < V || k <= 0 || (ids && ids_stride <= 0) || (!probs && !idx && !ids)) {
+        set_error("topk_sample: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (k > TOPK_MAX_K || k > V) { set_error("topk_sample: k=%d exceeds %d (or the vocabulary)", k, TOPK_MAX_K); return ICAP_ERR_LIMIT; }
+    if (V > 256 * TOPK_PER_THREAD) { set_error("topk_sample: V=%d exceeds %d", V, 256 * TOPK_PER_THREAD); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(topk_sample_kernel, dim3(rows), dim3(256), 0, st, logits, ld, V, k, seed, offset, probs, idx, ids, ids_stride);
+    return launch_status("topk_sample");
+}
+
 // ---------------------------------------------------------------- next token (arg-max finalize + gather + LayerNorm)
 // One wave per caption: reduce the arg-max partials of the vocabulary GEMM to the token id, store it at
 // ids[r * ids_stride], then build the next step's input row out[r] = LN(table[id] + add[r]) (LayerNorm only when

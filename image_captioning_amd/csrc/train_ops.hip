@@ -383,14 +383,6 @@ int axpby_f32(const float* x, float alpha, float beta, float* y, long long n, hi
 // Dropout with a counter-based generator: element i of call (seed, offset) keeps its value, scaled by 1/(1-p),
 // when hash(seed, offset + i) >= p.  mask[i] holds the factor that was applied (0 or 1/(1-p)), which is also the
 // gradient factor.  x may equal y.
-__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long idx) {
-    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float p, unsigned long long seed,
                                                       unsigned long long offset, long long n, long long group,
                                                       float* __restrict__ y, float* __restrict__ mask) {

@@ -269,6 +269,25 @@ def argmax_rows(logits, want_gap=False):
     return (idx, gap) if want_gap else idx
 
 
+def topk_sample(logits, k=10, seed=0, offset=0, ids_out=None, want_topk=True):
+    """softmax -> top-k -> one multinomial draw per row (the reference's generate_caption head).
+    logits [rows, V] (rows may be strided) -> (ids [rows] int64, probs [rows, k], idx [rows, k] int32).
+    ids_out: optional int64 column view (stride = its stride(0)) that receives the drawn tokens."""
+    if not isinstance(logits, torch.Tensor) or not logits.is_cuda or logits.dtype != torch.float32 or logits.stride(1) != 1:
+        raise IcapError("topk_sample: logits must be a float32 tensor on the HIP device with contiguous rows")
+    rows, V = logits.shape
+    dev = logits.device
+    ids = ids_out if ids_out is not None else torch.empty(rows, device=dev, dtype=torch.int64)
+    if ids.dtype != torch.int64 or ids.dim() != 1 or ids.shape[0] != rows:
+        raise IcapError("topk_sample: ids_out must be an int64 vector with one entry per row")
+    probs = torch.empty(rows, k, device=dev, dtype=torch.float32) if want_topk else None
+    idx = torch.empty(rows, k, device=dev, dtype=torch.int32) if want_topk else None
+    N.check(N.load().icap_topk_sample_f32(logits.data_ptr(), logits.stride(0), rows, V, k, int(seed) & (2 ** 64 - 1),
+                                          int(offset) & (2 ** 64 - 1), _ck(probs, "probs"), _ck(idx, "idx", torch.int32),
+                                          ids.data_ptr(), ids.stride(0), _stream()), "topk_sample")
+    return ids, probs, idx
+
+
 def linear_argmax(x, w, bias=None, scale=None, want_logits=False):
     """Vocabulary projection with fused arg-max partials -> (part_val [M,P], part_idx [M,P], logits or None)."""
     M, K = x.shape

@@ -137,6 +137,14 @@ int icap_layernorm_f32(const float* x, const float* res, int res_rows, const flo
 int icap_argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_stride, int rows, int V,
                          float* top2gap, void* stream);
 
+/* Top-k sampling head: per row softmax(logits[r][0..V)), its k (<= 16) most probable tokens - probs [rows][k] and
+ * idx [rows][k], most probable first - and ids[r*ids_stride] = one of them drawn with probability proportional to its
+ * softmax probability from the counter-based generator (row r of a call uses uniform(seed, offset + r), so a caller
+ * advances offset by `rows` per call).  probs / idx / ids are each optional.  The reference's generation mode:
+ * F.softmax -> torch.topk(probs, 10) -> torch.multinomial (TransformerTest.py:147-157). */
+int icap_topk_sample_f32(const float* logits, int ld, int rows, int V, int k, unsigned long long seed,
+                         unsigned long long offset, float* probs, int* idx, long long* ids, int ids_stride, void* stream);
+
 /* Scaled-dot-product attention after the input projections, sequence-first layout:
  * q [Lq][N][E], k/v [Lk][Nk][E] with Nk = N or 1.  nn.MultiheadAttention core:
  * transformer_word_level.py:45,74; transformer_word_level_bahdnau.py:74. */

@@ -141,7 +141,7 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         gi_emb = ops.linear(emb_all, w_ih_e, b_ih.detach()).view(Tn, B, 4 * H)
         u = _lin(feats, U_w, U_b)
         a_w = A_w.detach().view(-1).contiguous()
-        a_b = float(A_b.detach().item())
+        a_b = 0.0   # the scoring bias shifts every score of a softmax row alike: no effect on alpha, and no host read-back
         h = torch.zeros(B, H, device=dev)
         c = torch.zeros(B, H, device=dev)
         Hprev = torch.empty(Tn, B, H, device=dev)      # h_{t-1}

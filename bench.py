@@ -33,6 +33,7 @@ VOCAB = 6756          # word vocabulary of the full dataset (notebook cell 5)
 CAPTION_LEN = 20      # greedy tokens per caption (BASELINE: 20-token titles)
 HBM_PEAK_GBS = 8000.0
 F32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 (no sparsity)
 
 
 def parse():
@@ -41,6 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("caption", "train"), default="caption")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="compute dtype of the captioning GEMMs: f32 (default, the reference's), or bf16 products with fp32 "
+                         "accumulation and fp32 tensors in memory (captioning mode only)")
     ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 1024 captioning, 256 training)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,7 +90,7 @@ def stem_dw_work(sig):
     return 2.0 * B * Hs * Ws * 27 * C + 2.0 * B * Ho * Wo * C * 9, 4.0 * (B * H * W * 4 + B * Ho * Wo * C)
 
 
-WORK = {"stem_dwconv2d": stem_dw_work, "conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work, "expand_dwconv2d": expand_dw_work,
+WORK = {"linear_bf16": lambda s: linear_work(s[:4]), "stem_dwconv2d": stem_dw_work, "conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work, "expand_dwconv2d": expand_dw_work,
         # training-step launches: (flops, algorithmic bytes)
         "gemm_nn": gemm_work, "gemm_tn": gemm_work,
         "col_reduce": lambda s: (2.0 * s[1] * s[2], 4.0 * s[1] * s[2] * (2 if s[0] >= 2 else 1)),
@@ -116,6 +120,8 @@ def main():
 
     from image_captioning_amd import ops
     from image_captioning_amd import transformer_word_level as twl
+    if args.mode != "train":
+        ops.set_compute_dtype(args.dtype)
     from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images
 
     train = args.mode == "train"
@@ -203,11 +209,12 @@ def main():
         dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom_events) / max(len(dom_events), 1)
         flops, byts = WORK[dom["name"]](dom["sig"])
         hbm_t = byts / (HBM_PEAK_GBS * 1e9)
-        mfma_t = flops / (F32_MFMA_PEAK_TFLOPS * 1e12)
+        mfma_peak = BF16_MFMA_PEAK_TFLOPS if dom["name"] == "linear_bf16" else F32_MFMA_PEAK_TFLOPS
+        mfma_t = flops / (mfma_peak * 1e12)
         if hbm_t >= mfma_t:
             roof = {"bound": "hbm", "achieved": byts / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         else:
-            roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": mfma_peak, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["kernel"] = f"{dom['name']}{list(dom['sig'])}"
         roof["traffic"] = pmc_traffic(roof["kernel"])
@@ -225,7 +232,7 @@ def main():
             "metric": "captions/sec greedy + train imgs/sec, 224px food imgs, 1/2/4/8 MI355X",
             "value": captions / elapsed, "unit": "imgs/s" if train else "captions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if (train or args.dtype == "f32") else "bf16 products / f32 accumulate and storage", "data": "synthetic",
             "config": {"workload": workload, "images_per_step_per_gpu": B, "image": "3x224x224 fp32", "caption_tokens": CAPTION_LEN,
                        "vocab": VOCAB, "weights": "seeded random init", "parallelism": par},
             "roofline": roof,

@@ -244,16 +244,31 @@ class ImageCaptioningModelBase(nn.Module):
         xin, _ = ops.embedding(wd["emb"], start, add=ca)
         x = ops.layernorm(xin, wd["ln2_g"], wd["ln2_b"])
         all_logits = []
+        bf16 = ops.compute_dtype() == "bf16" and wd["fc1_w"].shape[1] % 8 == 0
+        if bf16 and "fc1_w16" not in wd:
+            wd["fc1_w16"], wd["out_w16"] = ops.to_bf16(wd["fc1_w"]), ops.to_bf16(wd["out_w4"])
+        V = wd["out_w"].shape[0]
         for t in range(max_len):
-            h = ops.linear(x, wd["fc1_w"], wd["fc1_b"], act=ops.ACT_RELU)
-            f = ops.linear(h, wd["fc2_w"], wd["fc2_b"], residual=x)
-            x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
-            pv, pi, logits = ops.linear_argmax(x2, wd["out_w4"], wd["out_b4"], want_logits=want_logits)
             last = t + 1 == max_len
-            x = ops.next_token(pv, pi, ids, t, None if last else wd["emb"], None if last else ca,
-                               None if last else wd["ln2_g"], None if last else wd["ln2_b"])
+            if bf16:
+                # bf16 products for the two wide GEMMs (fc2 has too few output tiles to gain); full logits, row arg-max
+                h = ops.linear_bf16(x, wd["fc1_w16"], wd["fc1_b"], act=ops.ACT_RELU)
+                f = ops.linear(h, wd["fc2_w"], wd["fc2_b"], residual=x)
+                x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
+                logits = ops.linear_bf16(x2, wd["out_w16"], wd["out_b4"])
+                ids[:, t] = ops.argmax_rows(logits)          # padded vocabulary rows carry a bias no real logit reaches
+                if not last:
+                    xin, _ = ops.embedding(wd["emb"], ids[:, t].contiguous(), add=ca)
+                    x = ops.layernorm(xin, wd["ln2_g"], wd["ln2_b"])
+            else:
+                h = ops.linear(x, wd["fc1_w"], wd["fc1_b"], act=ops.ACT_RELU)
+                f = ops.linear(h, wd["fc2_w"], wd["fc2_b"], residual=x)
+                x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
+                pv, pi, logits = ops.linear_argmax(x2, wd["out_w4"], wd["out_b4"], want_logits=want_logits)
+                x = ops.next_token(pv, pi, ids, t, None if last else wd["emb"], None if last else ca,
+                                   None if last else wd["ln2_g"], None if last else wd["ln2_b"])
             if want_logits:
-                all_logits.append(logits[:, :wd["out_w"].shape[0]])
+                all_logits.append(logits[:, :V])
         return (ids, torch.stack(all_logits, 0)) if want_logits else ids
 
     def sample_ids_from_features(self, img_embed, max_len, top_k=10, seed=0):

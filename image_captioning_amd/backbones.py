@@ -325,7 +325,7 @@ class EfficientNetB0(nn.Module):
             h, part = ops.stem_dwconv2d(x, p["stem_w"], *p["stem_sb"], d0["dw_w"], *d0["dw_sb"], stem_pad=(lo, hi, lo, hi),
                                         pad=(1, 1, 1, 1), want_partial=True)
             gate = ops.se_gate(part, h.shape[1] * h.shape[2], *d0["se"])
-            x = ops.conv2d(h, d0["proj"][0], *d0["proj"][1], gate=gate)
+            x = ops.pointwise_conv(h, d0["proj"][0], d0, "proj16", *d0["proj"][1], gate=gate)
             blocks = blocks[1:]
         else:
             x = ops.conv2d(x, p["stem_w"], *p["stem_sb"], stride=2, pad=(lo, hi, lo, hi), act=ops.ACT_SWISH)
@@ -341,12 +341,12 @@ class EfficientNetB0(nn.Module):
                                               stride=d["stride"], pad=pad, want_partial=True)
             else:
                 if d["expand"] is not None:
-                    h = ops.conv2d(h, d["expand"][0], *d["expand"][1], act=ops.ACT_SWISH)
+                    h = ops.pointwise_conv(h, d["expand"][0], d, "expand16", *d["expand"][1], act=ops.ACT_SWISH)
                 h, part = ops.dwconv2d(h, d["dw_w"], *d["dw_sb"], ks=d["k"], stride=d["stride"], pad=pad,
                                        act=ops.ACT_SWISH, want_partial=True)
             gate = ops.se_gate(part, h.shape[1] * h.shape[2], *d["se"])
-            x = ops.conv2d(h, d["proj"][0], *d["proj"][1], residual=inp if d["skip"] else None, gate=gate)
-        x = ops.conv2d(x, p["head_w"], *p["head_sb"], act=ops.ACT_SWISH)
+            x = ops.pointwise_conv(h, d["proj"][0], d, "proj16", *d["proj"][1], residual=inp if d["skip"] else None, gate=gate)
+        x = ops.pointwise_conv(x, p["head_w"], p, "head16", *p["head_sb"], act=ops.ACT_SWISH)
         x = ops.adaptive_avgpool2d(x, 1, 1)
         return x.view(x.shape[0], 1280)
 

@@ -1,0 +1,264 @@
+// Linear layers / 1x1 convolutions on the bf16 matrix cores with fp32 activations in memory:
+//   y[M][N] = act((x[M][K] (* gate[m / hw][k]) @ w[N][K]^T) * scale[n] + bias[n] (+ residual[m][n]))
+// x, y, scale, bias, residual, gate are fp32; w is bf16 (converted once when the weights are prepared).  The A operand
+// is rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32) while it is staged into LDS, products are accumulated
+// in fp32 by v_mfma_f32_32x32x16_bf16 - the "bf16 compute, fp32 storage" mode of the captioning path.
+//
+// A workgroup (4 waves, 2 x 2) owns a BM x BN output tile; operand tiles of 32 K elements are staged global ->
+// registers -> LDS (double buffered, one barrier per step), LDS rows are padded to 80 bytes so that the 16-byte
+// fragment reads (lane (r, h) reads k = 8h .. 8h+7 of row r) are conflict free.  The epilogue transposes the
+// accumulators through LDS and writes 16 bytes per lane along the output row.
+#include "common.hpp"
+
+namespace icap {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2b __attribute__((ext_vector_type(2)));
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+
+struct GemmBf16Params {
+    const float* x;
+    const unsigned short* w;
+    const float* scale;
+    const float* bias;
+    const float* residual;
+    const float* gate;      // [M / hw][K] or null
+    float* y;
+    int M, N, K, hw, act, tiles_n;
+};
+
+constexpr int GB16_BK = 32;             // K elements per step (two MFMA K blocks)
+constexpr int GB16_LDK = GB16_BK + 8;   // padded LDS row, bf16 elements (80 bytes)
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2b v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+template <int BM, int BN, bool GATE>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) {
+    constexpr int BK = GB16_BK, LDK = GB16_LDK;
+    constexpr int TM = BM / 2, TN = BN / 2, RM = TM / 32, RN = TN / 32;
+    constexpr int AP = BM / 32;                    // staging passes over A: thread t -> row t/8 + 32 i, floats 4 (t%8) ..
+    constexpr int BP = (BN + 63) / 64;             // staging passes over W: thread t -> row t/4 + 64 i, bf16 8 (t%4) ..
+    constexpr int EP_LD = BN + 4;
+    constexpr int EP_ROWS = BM < 64 ? BM : 64;
+    constexpr int STAGE_BYTES = 2 * (BM + BN) * LDK * 2;
+    constexpr int EP_BYTES = EP_ROWS * EP_LD * 4;
+    constexpr int SMEM_BYTES = STAGE_BYTES > EP_BYTES ? STAGE_BYTES : EP_BYTES;
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is built from 32x32 blocks");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem);            // [2][BM][LDK]
+    unsigned short* Bs = As + 2 * BM * LDK;                                  // [2][BN][LDK]
+    float* ep = reinterpret_cast<float*>(smem);                              // [EP_ROWS][EP_LD], used after the K loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // staging coordinates
+    const int a_k4 = (tid & 7) * 4, a_row = tid >> 3;
+    const int b_k8 = (tid & 3) * 8, b_row = tid >> 2;
+    const float* a_src[AP];
+    const float* g_src[GATE ? AP : 1];
+    bool a_ok[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + a_row + 32 * i;
+        a_ok[i] = m < p.M;
+        a_src[i] = p.x + (size_t)(a_ok[i] ? m : 0) * p.K;
+        if (GATE) g_src[i] = p.gate + (size_t)((a_ok[i] ? m : 0) / p.hw) * p.K;
+    }
+    const unsigned short* b_src[BP];
+    bool b_ok[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int n = n0 + b_row + 64 * i;
+        b_ok[i] = (b_row + 64 * i < BN) && n < p.N;
+        b_src[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K;
+    }
+
+    float4 ra[AP], rg[GATE ? AP : 1];
+    uint4 rb[BP];
+    unsigned okmask = 0;
+    // every load is unconditional (clamped address); out-of-range elements are zeroed when the slice goes to LDS
+    auto gload = [&](int t) {
+        const int ka = t * BK + a_k4, kb = t * BK + b_k8;
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const bool ok = a_ok[i] && ka < p.K;
+            ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ka : p.x);
+            if (GATE) rg[i] = *reinterpret_cast<const float4*>(ok ? g_src[i] + ka : p.gate);
+            okmask |= ok ? (1u << i) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const bool ok = b_ok[i] && kb < p.K;
+            rb[i] = *reinterpret_cast<const uint4*>(ok ? b_src[i] + kb : p.w);
+            okmask |= ok ? (1u << (16 + i)) : 0u;
+        }
+    };
+    auto lds_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            float4 v = ra[i];
+            if (GATE) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+            uint2 o = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            if (!((okmask >> i) & 1u)) o = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(&As[(buf * BM + a_row + 32 * i) * LDK + a_k4]) = o;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            if (BN % 64 == 0 || b_row + 64 * i < BN) {
+                const uint4 o = ((okmask >> (16 + i)) & 1u) ? rb[i] : make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(&Bs[(buf * BN + b_row + 64 * i) * LDK + b_k8]) = o;
+            }
+        }
+    };
+
+    f32x16b acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int koff = s * 16 + 8 * lh;
+            bf16x8 af[RM], bf[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&As[(buf * BM + wm * TM + i * 32 + lr) * LDK + koff]));
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+                bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[(buf * BN + wn * TN + j * 32 + lr) * LDK + koff]));
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    lds_store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nk; ++t) {
+        const bool more = t + 1 < nk;
+        if (more) gload(t + 1);
+        compute(cur);
+        if (more) lds_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: accumulators -> LDS (row-major) -> 16-byte stores along the output row ----
+    constexpr int BN4 = BN / 4;
+    constexpr int EP_RPI = 256 / BN4;              // rows covered per pass of the workgroup
+    constexpr int NPASS = BM / EP_ROWS;
+    const int en4 = tid % BN4, erow = tid / BN4;
+    const int n = n0 + en4 * 4;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < p.N) {
+        if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
+        if (p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + n);
+    }
+    dispatch_act(p.act, [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int r0 = pass * EP_ROWS;
+            if (wm * TM >= r0 && wm * TM < r0 + EP_ROWS) {
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int row = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh - r0;
+                            ep[row * EP_LD + wn * TN + j * 32 + lr] = acc[i][j][e];
+                        }
+            }
+            __syncthreads();
+            for (int row = erow; row < EP_ROWS; row += EP_RPI) {
+                const int m = m0 + r0 + row;
+                if (m >= p.M || n >= p.N) continue;
+                float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
+                v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
+                v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
+                const size_t o = (size_t)m * p.N + n;
+                if (p.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + o);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                v.x = act_c<ACT>(v.x); v.y = act_c<ACT>(v.y); v.z = act_c<ACT>(v.z); v.w = act_c<ACT>(v.w);
+                *reinterpret_cast<float4*>(p.y + o) = v;
+            }
+            __syncthreads();
+        }
+    });
+}
+
+template <int BM, int BN>
+static void gb16_launch(GemmBf16Params& p, hipStream_t st) {
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const long long tiles = (long long)((p.M + BM - 1) / BM) * p.tiles_n;
+    if (p.gate) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+}
+
+// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles.
+int linear_bf16_f32(const float* x, const unsigned short* w, const float* scale, const float* bias, const float* residual,
+                    const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, hipStream_t st) {
+    if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0 || (gate && hw <= 0)) { set_error("linear_bf16: bad arguments"); return ICAP_ERR_ARG; }
+    if (K % 8 || N % 4) { set_error("linear_bf16: K=%d must be a multiple of 8 and N=%d of 4", K, N); return ICAP_ERR_ALIGN; }
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (scale && !aligned16(scale)) || (bias && !aligned16(bias)) ||
+        (residual && !aligned16(residual)) || (gate && !aligned16(gate))) {
+        set_error("linear_bf16: pointers must be 16-byte aligned");
+        return ICAP_ERR_ALIGN;
+    }
+    if ((long long)M * N > (1LL << 40) || (long long)((M + 63) / 64) * ((N + 63) / 64) > 0x7fffffffLL) {
+        set_error("linear_bf16: problem too large");
+        return ICAP_ERR_LIMIT;
+    }
+    GemmBf16Params p{x, w, scale, bias, residual, gate, y, M, N, K, gate ? hw : 1, act, 0};
+    if (cfg < 0) {
+        const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+        if (N > 64 && t128 >= 512) cfg = 0;
+        else if ((long long)((M + 127) / 128) * ((N + 63) / 64) >= 512) cfg = 1;
+        else cfg = 2;
+    }
+    switch (cfg) {
+        case 0: gb16_launch<128, 128>(p, st); break;
+        case 1: gb16_launch<128, 64>(p, st); break;
+        case 2: gb16_launch<64, 64>(p, st); break;
+        default: set_error("linear_bf16: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
+    }
+    return launch_status("linear_bf16");
+}
+
+// fp32 -> bf16 (round to nearest even), n a multiple of 2
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, long long n2) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256)
+        dst[i] = pack_bf16(src[2 * i], src[2 * i + 1]);
+}
+
+int to_bf16_f32(const float* src, unsigned short* dst, long long n, hipStream_t st) {
+    if (!src || !dst || n <= 0 || (n & 1)) { set_error("to_bf16: bad arguments (n must be even)"); return ICAP_ERR_ARG; }
+    long long blocks = (n / 2 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, reinterpret_cast<unsigned*>(dst), n / 2);
+    return launch_status("to_bf16");
+}
+
+}  // namespace icap

@@ -25,6 +25,38 @@ AUTOTUNE = False
 _tuned_shapes = set()
 
 
+COMPUTE_DTYPE = "f32"
+
+
+def set_compute_dtype(name: str) -> None:
+    """"f32" (default): every product in fp32.  "bf16": the 1x1 convolutions of the EfficientNet encoder and the wide
+    decoder GEMMs (fc1, vocabulary projection) of the batched greedy path multiply bf16-rounded operands on the bf16
+    matrix cores and accumulate in fp32; every tensor in memory stays fp32."""
+    global COMPUTE_DTYPE
+    if name not in ("f32", "bf16"):
+        raise IcapError(f"set_compute_dtype: unknown dtype {name!r}")
+    COMPUTE_DTYPE = name
+
+
+def compute_dtype() -> str:
+    return COMPUTE_DTYPE
+
+
+def pointwise_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None, gate=None, act=ACT_NONE):
+    """1x1 convolution x [B,H,W,Cin] with w [Cout,1,1,Cin]: the fp32 implicit-GEMM kernel, or - in bf16 compute mode and
+    for shapes the bf16 kernel accepts - icap_linear_bf16_f32 with a cached bf16 copy of the weight."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if COMPUTE_DTYPE == "bf16" and Cin % 8 == 0 and Cout % 4 == 0:
+        w16 = w16_cache.get(key)
+        if w16 is None:
+            w16 = w16_cache[key] = to_bf16(w.reshape(Cout, Cin).contiguous())
+        y = linear_bf16(x.view(B * H * W, Cin), w16, bias, scale, act=act,
+                        residual=residual.view(B * H * W, Cout) if residual is not None else None, gate=gate, hw=H * W)
+        return y.view(B, H, W, Cout)
+    return conv2d(x, w, scale, bias, residual=residual, gate=gate, act=act)
+
+
 def set_autotune(flag: bool) -> None:
     global AUTOTUNE
     AUTOTUNE = bool(flag)
@@ -267,6 +299,37 @@ def argmax_rows(logits, want_gap=False):
     N.check(N.load().icap_argmax_rows_f32(_ck(logits, "logits"), V, _ck(idx, "idx", torch.int64), 1, rows, V,
                                           _ck(gap, "gap"), _stream()), "argmax_rows")
     return (idx, gap) if want_gap else idx
+
+
+def to_bf16(w: torch.Tensor) -> torch.Tensor:
+    """fp32 tensor -> bf16 copy (round to nearest even), same shape."""
+    n = w.numel()
+    if n % 2:
+        raise IcapError("to_bf16: element count must be even")
+    out = torch.empty(w.shape, device=w.device, dtype=torch.bfloat16)
+    N.check(N.load().icap_to_bf16_f32(_ck(w, "w"), out.data_ptr(), n, _stream()), "to_bf16")
+    return out
+
+
+def linear_bf16(x, w_bf16, bias=None, scale=None, act=ACT_NONE, residual=None, gate=None, hw=1, out=None, cfg=-1):
+    """y[M,N] = act((x[M,K] (* gate[m // hw]) @ w[N,K]^T) * scale + bias (+ residual)) with bf16 products, fp32
+    accumulation and fp32 tensors in memory; w_bf16 from to_bf16()."""
+    M, K = x.shape
+    Nn, K2 = w_bf16.shape[0], w_bf16.numel() // w_bf16.shape[0]
+    if K != K2 or w_bf16.dtype != torch.bfloat16:
+        raise IcapError(f"linear_bf16: x has K={K}, w must be bf16 [N, {K}]")
+    if out is None:
+        out = torch.empty((M, Nn), device=x.device, dtype=torch.float32)
+    if residual is not None and residual.numel() != M * Nn:
+        raise IcapError("linear_bf16: residual has the wrong size")
+    if gate is not None and (gate.shape[-1] != K or gate.shape[0] * hw != M):
+        raise IcapError("linear_bf16: gate must be [M // hw, K]")
+    span = _Span("linear_bf16", (M, K, Nn, residual is not None, gate is not None))
+    N.check(N.load().icap_linear_bf16_f32(_ck(x, "x"), _ck(w_bf16, "w", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
+                                          _ck(residual, "residual"), _ck(gate, "gate"), hw, _ck(out, "out"), M, K, Nn, act, cfg,
+                                          _stream()), "linear_bf16")
+    span.done()
+    return out
 
 
 def topk_sample(logits, k=10, seed=0, offset=0, ids_out=None, want_topk=True):

@@ -137,6 +137,17 @@ int icap_layernorm_f32(const float* x, const float* res, int res_rows, const flo
 int icap_argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_stride, int rows, int V,
                          float* top2gap, void* stream);
 
+/* bf16-compute form of a Linear layer / 1x1 convolution (fp32 tensors in memory, bf16 weights, fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16):  y[M][N] = act((x[M][K] (* gate[m / hw][k]) @ w^T) * scale[n] + bias[n] (+ residual[m][n])),
+ * w_bf16 [N][K] as produced by icap_to_bf16_f32 (round to nearest even).  K % 8 == 0, N % 4 == 0.  cfg -1 picks the
+ * tile shape (0: 128x128, 1: 128x64, 2: 64x64).  Same layers as icap_conv2d_f32 with KH = KW = 1 - MBConv `_expand_conv`,
+ * `_project_conv`, `_conv_head` (transformer_word_level.py:13) and every nn.Linear of the decoders - at the precision
+ * north-star configuration names for the accelerated path. */
+int icap_linear_bf16_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias,
+                         const float* residual, const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg,
+                         void* stream);
+int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* stream);
+
 /* Top-k sampling head: per row softmax(logits[r][0..V)), its k (<= 16) most probable tokens - probs [rows][k] and
  * idx [rows][k], most probable first - and ids[r*ids_stride] = one of them drawn with probability proportional to its
  * softmax probability from the counter-based generator (row r of a call uses uniform(seed, offset + r), so a caller

@@ -305,3 +305,33 @@ def test_argument_errors_are_raised():
         ops.conv2d(torch.zeros(1, 4, 4, 6, device=d), torch.zeros(8, 1, 1, 6, device=d))   # Cin % 4
     with pytest.raises(ops.IcapError):
         ops.gemv(torch.zeros(16, 8, device=d), torch.zeros(9, 8, device=d))    # more than 8 lock-step rows
+
+
+@pytest.mark.parametrize("M,K,N,act,use_res,use_gate,cfg", [
+    (300, 512, 6756, 0, False, False, -1), (1000, 112, 672, 2, False, False, 0), (392, 672, 112, 0, True, True, 1),
+    (50, 16, 96, 2, False, False, 2), (98, 1152, 320, 0, False, True, -1), (7, 2048, 512, 1, True, False, -1),
+    (260, 40, 240, 2, False, False, 0)])
+def test_linear_bf16(M, K, N, act, use_res, use_gate, cfg):
+    """bf16 products / fp32 accumulation: exact against the same computation on bf16-rounded operands (the rounding is
+    the only difference from the fp32 kernel), and within the stated bf16 tolerance of the unrounded result."""
+    from image_captioning_amd import ops
+    d = dev()
+    hw = 49 if use_gate else 1
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    scale = torch.rand(N, generator=torch.Generator().manual_seed(4)) + 0.5
+    res = rnd(M, N, seed=5) if use_res else None
+    gate = torch.rand(M // hw, K, generator=torch.Generator().manual_seed(6)) if use_gate else None
+    xg = x * gate.repeat_interleave(hw, 0) if use_gate else x
+    w16 = ops.to_bf16(w.to(d))
+    assert torch.equal(w16.cpu(), w.to(torch.bfloat16))                       # round to nearest even, like torch
+    got = ops.linear_bf16(x.to(d), w16, b.to(d), scale.to(d), act=act, residual=res.to(d) if use_res else None,
+                          gate=gate.to(d) if use_gate else None, hw=hw, cfg=cfg)
+
+    def ref(xa, wa):
+        y = (xa.double() @ wa.double().t()) * scale.double() + b.double()
+        if use_res:
+            y = y + res.double()
+        return act_ref(y, act).float()
+    exact = ref(xg.to(torch.bfloat16).float(), w.to(torch.bfloat16).float())
+    close(got, exact, rtol=1e-4, atol=1e-4, what="linear_bf16 vs bf16-rounded operands")
+    close(got, ref(xg, w), rtol=2e-2, atol=2e-2, what="linear_bf16 vs fp32 (bf16 tolerance: 2e-2)")

@@ -36,10 +36,10 @@ int dwconv2d_f32(const float*, const float*, const float*, const float*, float*,
                  int, int, int, int, int, hipStream_t);
 int dwconv_chunks(int, int, int, int, int);
 int expand_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
-                      float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+                      float*, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int expand_dwconv_chunks(int, int, int, int, int, int);
 int stem_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
-                    float*, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+                    float*, int, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int stem_dwconv_chunks(int, int, int);
 int se_gate_f32(const float*, int, float, const float*, const float*, const float*, const float*, float*, int, int, int,
                 hipStream_t);
@@ -178,7 +178,14 @@ int icap_expand_dwconv_f32(const float* x, const float* w_exp, const float* exp_
                            const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int H, int W, int Cin,
                            int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
     return expand_dwconv_f32(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, y, partial, B, H, W, Cin, Cexp, KS, stride,
-                             pad_t, pad_l, Ho, Wo, (hipStream_t)stream);
+                             pad_t, pad_l, Ho, Wo, 0, (hipStream_t)stream);
+}
+
+int icap_expand_dwconv_bf16_f32(const float* x, const float* w_exp, const float* exp_scale, const float* exp_bias, const float* w_dw,
+                                const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int H, int W, int Cin,
+                                int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+    return expand_dwconv_f32(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, y, partial, B, H, W, Cin, Cexp, KS, stride,
+                             pad_t, pad_l, Ho, Wo, 1, (hipStream_t)stream);
 }
 
 int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias, const float* w_dw,
@@ -186,7 +193,15 @@ int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_
                          int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,
                          void* stream) {
     return stem_dwconv_f32(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, y, partial, B, img_h, img_w, Hs, Ws, C,
-                           stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, (hipStream_t)stream);
+                           stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, 0, (hipStream_t)stream);
+}
+
+int icap_stem_dwconv_bf16_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias, const float* w_dw,
+                              const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int img_h, int img_w,
+                              int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,
+                              void* stream) {
+    return stem_dwconv_f32(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, y, partial, B, img_h, img_w, Hs, Ws, C,
+                           stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, 1, (hipStream_t)stream);
 }
 
 int icap_stem_dwconv_chunks(int Ho, int Wo, int C) { return stem_dwconv_chunks(Ho, Wo, C); }

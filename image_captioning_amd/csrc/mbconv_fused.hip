@@ -19,21 +19,25 @@
 namespace icap {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 xd_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XD_CC = 32;            // expanded channels per chunk (one MFMA column block)
 constexpr int XD_LDE = XD_CC + 4;    // padded row of E (16-byte aligned rows, consecutive pixels start 4 banks apart)
 
 // Workgroups whose LDS footprint fits a CU three times are compiled for three waves per SIMD, the others for two.
-template <int KS, int S, int TH, int TW>
+template <int KS, int S, int TH, int TW, bool WIDE = false>
 constexpr int xd_waves() {
+    if (WIDE) return 2;   // the stem's bf16 variant holds the fp32 patch and its packed copy at once: 256-register budget
     return ((((TH - 1) * S + KS) * ((TW - 1) * S + KS) + 31) / 32) * 32 * XD_LDE * 4 + 2 * (KS * KS + 1) * 128 + 512 <= 160 * 1024 / 3 ? 3 : 2;
 }
 
 // STEM: the first convolution is not a 1x1 expand but EfficientNet's 3x3 stride-2 stem on the 4-channel-padded image
 // (x [B][img_h][img_w][4], we [Cexp][3][3][4]): the GEMM's K axis is the 36-element patch, padded to 40 (ten taps, five per
 // lane half, the tenth zero), gathered straight from the image; H x W is then the stem's OUTPUT size.
-template <int CIN, int KS, int S, int TH, int TW, int SW, bool STEM = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS, S, TH, TW>()))) void expand_dw_kernel(
+template <int CIN, int KS, int S, int TH, int TW, int SW, bool STEM = false, bool BF16 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS, S, TH, TW, STEM && BF16>()))) void expand_dw_kernel(
     const float* __restrict__ x, const float* __restrict__ we, const float* __restrict__ es, const float* __restrict__ eb,
     const float* __restrict__ wd, const float* __restrict__ dsc, const float* __restrict__ dbi, float* __restrict__ y,
     float* __restrict__ partial, int H, int W, int Cexp, int pad_t, int pad_l, int Ho, int Wo, int tiles_w, int cpg,
@@ -148,6 +152,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
         }
     };
     auto fold_dw = [&](const float4& v, const float4& s4) { return make_float4(v.x * s4.x, v.y * s4.y, v.z * s4.z, v.w * s4.w); };
+    // bf16 products (BF16): a lane's KH2 values become ceil(KH2 / 8) packed chunks of 8 (zero padded); chunk c of both
+    // lane halves is one K = 16 block of v_mfma_f32_32x32x16_bf16 - A and B use the same assignment, so any works
+    constexpr int NCH = (KH2 + 7) / 8;
+    auto pack8 = [&](const float (&f)[KH2], uint4 (&o)[NCH]) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 8 * c + 2 * j;
+                const xd_f32x2 v = {k < KH2 ? f[k < KH2 ? k : 0] : 0.f, k + 1 < KH2 ? f[k + 1 < KH2 ? k + 1 : 0] : 0.f};
+                w[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, xd_bf16x2));
+            }
+            o[c] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    };
+    uint4 a16[BF16 ? NRB : 1][NCH], b16[NCH];
     const int ch_begin = blockIdx.z * cpg;
     {
         float braw[KH2], s_;
@@ -155,6 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
         float4 wv, ws4;
         load_dw_params(ch_begin, wv, ws4);
         fold_b(bf, braw, s_);
+        if constexpr (BF16) pack8(bf, b16);
         if (wrow < WROWS) Wl[ch_begin & 1][wrow][q] = fold_dw(wv, ws4);
     }
 
@@ -181,8 +203,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
                     f32x16 acc;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[e] = bi;
+                    if constexpr (BF16) {
+                        if (ch == ch_begin) pack8(af[i], a16[i]);
 #pragma unroll
-                    for (int s = 0; s < KH2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[s], acc, 0, 0, 0);
+                        for (int c = 0; c < NCH; ++c)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xd_bf16x8, a16[i][c]),
+                                                                          __builtin_bit_cast(xd_bf16x8, b16[c]), acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < KH2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[s], acc, 0, 0, 0);
+                    }
                     // swish stage by stage over all 16 accumulators, so that no exp2 / rcp result is needed right
                     // after it is issued
                     float r[16];
@@ -276,6 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
             *reinterpret_cast<float4*>(partial + ((size_t)b * gridDim.x + tile) * Cexp + c) = t;
         }
         fold_b(bf, bfn, scn);
+        if constexpr (BF16) pack8(bf, b16);
         bi = bin;
     }
 }
@@ -301,7 +332,7 @@ int expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int stride) 
 
 int expand_dwconv_f32(const float* x, const float* we, const float* es, const float* eb, const float* wd, const float* ds,
                       const float* db, float* y, float* partial, int B, int H, int W, int Cin, int Cexp, int KS, int stride,
-                      int pad_t, int pad_l, int Ho, int Wo, hipStream_t st) {
+                      int pad_t, int pad_l, int Ho, int Wo, int bf16, hipStream_t st) {
     if (!x || !we || !wd || !y || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || pad_t < 0 || pad_l < 0) {
         set_error("expand_dwconv: bad arguments");
         return ICAP_ERR_ARG;
@@ -331,9 +362,13 @@ int expand_dwconv_f32(const float* x, const float* we, const float* es, const fl
     const int cpg = (nchunks + zg - 1) / zg;
     zg = (nchunks + cpg - 1) / cpg;
     const dim3 grid(ntiles, B, zg), block(256);
-#define ICAP_XD(CIN_, KS_, S_, TH_, TW_, SW_)                                                                              \
-    hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_>), grid, block, 0, st, x, we, es, eb, wd, ds, db, y, \
-                       partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0)
+#define ICAP_XD(CIN_, KS_, S_, TH_, TW_, SW_)                                                                                     \
+    do {                                                                                                                          \
+        if (bf16) hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_, false, true>), grid, block, 0, st, x, we, es, \
+                                     eb, wd, ds, db, y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0);     \
+        else hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_>), grid, block, 0, st, x, we, es, eb, wd, ds, db,  \
+                                y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0);                          \
+    } while (0)
     if (Cin == 16) ICAP_XD(16, 3, 2, 7, 8, 2);
     else if (Cin == 24 && KS == 3) ICAP_XD(24, 3, 1, 14, 14, 7);
     else if (Cin == 24) ICAP_XD(24, 5, 2, 7, 7, 2);
@@ -354,7 +389,7 @@ int stem_dwconv_chunks(int Ho, int Wo, int C) {
 
 int stem_dwconv_f32(const float* x, const float* ws, const float* ss, const float* sb, const float* wd, const float* ds,
                     const float* db, float* y, float* partial, int B, int img_h, int img_w, int Hs, int Ws, int C,
-                    int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo, hipStream_t st) {
+                    int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo, int bf16, hipStream_t st) {
     if (!x || !ws || !wd || !y || B <= 0 || img_h <= 0 || img_w <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 ||
         C % 4 || stem_pad_t < 0 || stem_pad_l < 0 || pad_t < 0 || pad_l < 0) {
         set_error("stem_dwconv: bad arguments");
@@ -375,8 +410,10 @@ int stem_dwconv_f32(const float* x, const float* ws, const float* ss, const floa
     const int ntiles = ((Ho + STEM_TH - 1) / STEM_TH) * tiles_w;
     const int nchunks = (C + XD_CC - 1) / XD_CC;
     const dim3 grid(ntiles, B, 1), block(256);
-    hipLaunchKernelGGL((expand_dw_kernel<40, 3, 1, STEM_TH, STEM_TW, 7, true>), grid, block, 0, st, x, ws, ss, sb, wd, ds, db, y,
-                       partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l);
+    if (bf16) hipLaunchKernelGGL((expand_dw_kernel<40, 3, 1, STEM_TH, STEM_TW, 7, true, true>), grid, block, 0, st, x, ws, ss, sb, wd, ds,
+                                 db, y, partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l);
+    else hipLaunchKernelGGL((expand_dw_kernel<40, 3, 1, STEM_TH, STEM_TW, 7, true>), grid, block, 0, st, x, ws, ss, sb, wd, ds, db, y,
+                            partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l);
     return launch_status("stem_dwconv");
 }
 

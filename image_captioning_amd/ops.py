@@ -209,7 +209,8 @@ def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, k
     y = torch.empty((B, Ho, Wo, Cexp), device=x.device, dtype=torch.float32)
     partial = torch.empty((B, nch, Cexp), device=x.device, dtype=torch.float32) if want_partial else None
     span = _Span("expand_dwconv2d", (B, H, W, Cin, Cexp, ks, stride, Ho, Wo))
-    N.check(lib.icap_expand_dwconv_f32(_ck(x, "x"), _ck(w_exp, "w_exp"), _ck(exp_scale, "exp_scale"), _ck(exp_bias, "exp_bias"),
+    entry = lib.icap_expand_dwconv_bf16_f32 if COMPUTE_DTYPE == "bf16" else lib.icap_expand_dwconv_f32
+    N.check(entry(_ck(x, "x"), _ck(w_exp, "w_exp"), _ck(exp_scale, "exp_scale"), _ck(exp_bias, "exp_bias"),
                                        _ck(w_dw, "w_dw"), _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"), _ck(y, "y"),
                                        _ck(partial, "partial"), B, H, W, Cin, Cexp, ks, stride, pt, pl, Ho, Wo, _stream()),
             "expand_dwconv2d")
@@ -232,7 +233,8 @@ def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, 
     y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
     partial = torch.empty((B, lib.icap_stem_dwconv_chunks(Ho, Wo, Cc), Cc), device=x.device, dtype=torch.float32) if want_partial else None
     span = _Span("stem_dwconv2d", (B, H, W, Cc, Hs, Ws, Ho, Wo))
-    N.check(lib.icap_stem_dwconv_f32(_ck(x, "x"), _ck(w_stem, "w_stem"), _ck(stem_scale, "stem_scale"), _ck(stem_bias, "stem_bias"),
+    entry = lib.icap_stem_dwconv_bf16_f32 if COMPUTE_DTYPE == "bf16" else lib.icap_stem_dwconv_f32
+    N.check(entry(_ck(x, "x"), _ck(w_stem, "w_stem"), _ck(stem_scale, "stem_scale"), _ck(stem_bias, "stem_bias"),
                                      _ck(w_dw, "w_dw"), _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"), _ck(y, "y"),
                                      _ck(partial, "partial"), B, H, W, Hs, Ws, Cc, stem_pad[0], stem_pad[2], pad[0], pad[2], Ho, Wo,
                                      _stream()), "stem_dwconv2d")

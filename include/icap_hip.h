@@ -104,6 +104,18 @@ int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_
                          int Ho, int Wo, void* stream);
 int icap_stem_dwconv_chunks(int Ho, int Wo, int C);
 
+/* The two fused kernels with bf16 products in their first (expand / stem) convolution - operands rounded to bf16 in
+ * registers, fp32 accumulation on v_mfma_f32_32x32x16_bf16; the depthwise stage and every tensor in memory stay fp32.
+ * Same arguments and layouts as the fp32 forms above. */
+int icap_expand_dwconv_bf16_f32(const float* x, const float* w_exp, const float* exp_scale, const float* exp_bias,
+                                const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial,
+                                int B, int H, int W, int Cin, int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho,
+                                int Wo, void* stream);
+int icap_stem_dwconv_bf16_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias,
+                              const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial,
+                              int B, int img_h, int img_w, int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t,
+                              int pad_l, int Ho, int Wo, void* stream);
+
 /* Squeeze-excite gate: gate[b][c] = sigmoid(We . swish(Wr . mean_hw(x) + br) + be),
  * from the chunk sums written by icap_dwconv2d_f32.  wr [S][C]; we [S][C] (the expand weight TRANSPOSED).
  * Replaces MBConv `_se_reduce` / `_se_expand` (transformer_word_level.py:13). */

@@ -60,3 +60,35 @@ def test_compute_dtype_switch_and_fallback_shapes(bf16_mode):
     assert cache["k"].dtype == torch.bfloat16
     ref = torch.einsum("bhwc,oc->bhwo", x.to(torch.bfloat16).float(), w.view(20, 16).to(torch.bfloat16).float())
     assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("Cin,Cexp,H,W,ks,s,pad", [(16, 96, 37, 41, 3, 2, (0, 1, 0, 1)), (24, 144, 28, 30, 3, 1, (1, 1, 1, 1)),
+                                                    (24, 144, 29, 27, 5, 2, (1, 2, 1, 2)), (40, 240, 28, 17, 5, 1, (2, 2, 2, 2)),
+                                                    (40, 240, 28, 28, 3, 2, (0, 1, 0, 1))])
+def test_fused_expand_dwconv_bf16(bf16_mode, Cin, Cexp, H, W, ks, s, pad):
+    """The fused kernel with bf16 products in its expand GEMM: against torch on bf16-rounded expand operands (the BN scale
+    is folded into the weights before they are rounded, so the comparison allows a few bf16 ulps of the expanded value)."""
+    import torch.nn.functional as F
+    ops = bf16_mode
+    g = lambda seed: torch.Generator().manual_seed(seed)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g(1))
+    we = torch.randn(Cexp, Cin, 1, 1, generator=g(2)) * Cin ** -0.5
+    es, eb = torch.rand(Cexp, generator=g(3)) + 0.5, torch.randn(Cexp, generator=g(4)) * 0.3
+    wd = torch.randn(Cexp, 1, ks, ks, generator=g(5)) / ks
+    dsc, dbi = torch.rand(Cexp, generator=g(6)) + 0.5, torch.randn(Cexp, generator=g(7)) * 0.1
+    e = F.conv2d(x, we) * es[None, :, None, None] + eb[None, :, None, None]
+    e = e * torch.sigmoid(e)
+    ref = F.conv2d(F.pad(e, (pad[2], pad[3], pad[0], pad[1])), wd, stride=s, groups=Cexp) * dsc[None, :, None, None] + dbi[None, :, None, None]
+    ref = ref * torch.sigmoid(ref)
+    args = (x.permute(0, 2, 3, 1).contiguous().to(D), we.view(Cexp, Cin).contiguous().to(D), es.to(D), eb.to(D),
+            wd.view(Cexp, ks * ks).t().contiguous().to(D), dsc.to(D), dbi.to(D))
+    ops.set_compute_dtype("f32")
+    y32, _ = ops.expand_dwconv2d(*args, ks=ks, stride=s, pad=pad, want_partial=True)
+    ops.set_compute_dtype("bf16")
+    y16, part = ops.expand_dwconv2d(*args, ks=ks, stride=s, pad=pad, want_partial=True)
+    assert not torch.equal(y16, y32)
+    scale = float(ref.abs().max())
+    assert float((y16.permute(0, 3, 1, 2).cpu() - ref).abs().max()) <= 2e-2 * scale      # stated bf16 tolerance
+    assert float((y16 - y32).abs().max()) <= 2e-2 * scale
+    torch.testing.assert_close(part.sum(1).cpu() / (ref.shape[2] * ref.shape[3]), y16.mean((1, 2)).cpu(), rtol=1e-4, atol=1e-5)

@@ -251,15 +251,13 @@ class ImageCaptioningModelBase(nn.Module):
         for t in range(max_len):
             last = t + 1 == max_len
             if bf16:
-                # bf16 products for the two wide GEMMs (fc2 has too few output tiles to gain); full logits, row arg-max
+                # bf16 products for the two wide GEMMs (fc2 has too few output tiles to gain)
                 h = ops.linear_bf16(x, wd["fc1_w16"], wd["fc1_b"], act=ops.ACT_RELU)
                 f = ops.linear(h, wd["fc2_w"], wd["fc2_b"], residual=x)
                 x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
-                logits = ops.linear_bf16(x2, wd["out_w16"], wd["out_b4"])
-                ids[:, t] = ops.argmax_rows(logits)          # padded vocabulary rows carry a bias no real logit reaches
-                if not last:
-                    xin, _ = ops.embedding(wd["emb"], ids[:, t].contiguous(), add=ca)
-                    x = ops.layernorm(xin, wd["ln2_g"], wd["ln2_b"])
+                pv, pi, logits = ops.linear_bf16_argmax(x2, wd["out_w16"], wd["out_b4"], want_logits=want_logits)
+                x = ops.next_token(pv, pi, ids, t, None if last else wd["emb"], None if last else ca,
+                                   None if last else wd["ln2_g"], None if last else wd["ln2_b"])
             else:
                 h = ops.linear(x, wd["fc1_w"], wd["fc1_b"], act=ops.ACT_RELU)
                 f = ops.linear(h, wd["fc2_w"], wd["fc2_b"], residual=x)

@@ -30,6 +30,8 @@ int next_token_f32(const float*, const int*, int, long long*, int, const float*,
 int linear_bf16_f32(const float*, const unsigned short*, const float*, const float*, const float*, const float*, int, float*, int, int,
                     int, int, int, hipStream_t);
 int to_bf16_f32(const float*, unsigned short*, long long, hipStream_t);
+int linear_bf16_argmax_parts(int);
+int linear_bf16_argmax_f32(const float*, const unsigned short*, const float*, const float*, float*, float*, int*, int, int, int, hipStream_t);
 int topk_sample_f32(const float*, int, int, int, int, unsigned long long, unsigned long long, float*, int*, long long*, int, hipStream_t);
 int nchw_to_nhwc_pad_f32(const float*, float*, int, int, int, int, int, hipStream_t);
 int dwconv2d_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
@@ -156,6 +158,13 @@ int icap_linear_bf16_f32(const float* x, const unsigned short* w_bf16, const flo
                          const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, void* stream) {
     return linear_bf16_f32(x, w_bf16, scale, bias, residual, gate, hw, y, M, K, N, act, cfg, (hipStream_t)stream);
 }
+
+int icap_linear_bf16_argmax_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias, float* y,
+                                float* part_val, int* part_idx, int M, int K, int N, void* stream) {
+    return linear_bf16_argmax_f32(x, w_bf16, scale, bias, y, part_val, part_idx, M, K, N, (hipStream_t)stream);
+}
+
+int icap_linear_bf16_argmax_parts(int N) { return linear_bf16_argmax_parts(N); }
 
 int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* stream) {
     return to_bf16_f32(src, dst, n, (hipStream_t)stream);

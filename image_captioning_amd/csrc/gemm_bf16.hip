@@ -24,8 +24,10 @@ struct GemmBf16Params {
     const float* bias;
     const float* residual;
     const float* gate;      // [M / hw][K] or null
-    float* y;
+    float* y;               // may be null when only the arg-max partials are wanted
     int M, N, K, hw, act, tiles_n;
+    float* amax_val;        // optional [M][tiles_n]: per-tile row maxima of the outputs (arg-max partials)
+    int* amax_idx;          // their column indices (first index on ties)
 };
 
 constexpr int GB16_BK = 32;             // K elements per step (two MFMA K blocks)
@@ -36,7 +38,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-template <int BM, int BN, bool GATE>
+template <int BM, int BN, bool GATE, bool AMAX = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) {
     constexpr int BK = GB16_BK, LDK = GB16_LDK;
     constexpr int TM = BM / 2, TN = BN / 2, RM = TM / 32, RN = TN / 32;
@@ -192,6 +194,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
             __syncthreads();
             for (int row = erow; row < EP_ROWS; row += EP_RPI) {
                 const int m = m0 + r0 + row;
+                if constexpr (AMAX) {
+                    // row maximum over this tile's columns: the BN4 lanes holding one row are contiguous in the wave
+                    float bv = -INFINITY;
+                    int bidx = 0x7fffffff;
+                    if (m < p.M && n < p.N) {
+                        float4 t4 = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
+                        t4.x = act_c<ACT>(fmaf(t4.x, sc4.x, bi4.x)); t4.y = act_c<ACT>(fmaf(t4.y, sc4.y, bi4.y));
+                        t4.z = act_c<ACT>(fmaf(t4.z, sc4.z, bi4.z)); t4.w = act_c<ACT>(fmaf(t4.w, sc4.w, bi4.w));
+                        bv = t4.x; bidx = n;
+                        argmax_combine(bv, bidx, t4.y, n + 1);
+                        argmax_combine(bv, bidx, t4.z, n + 2);
+                        argmax_combine(bv, bidx, t4.w, n + 3);
+                    }
+#pragma unroll
+                    for (int o2 = BN4 / 2; o2 > 0; o2 >>= 1) {
+                        const float ov = __shfl_xor(bv, o2, 64);
+                        const int oi = __shfl_xor(bidx, o2, 64);
+                        argmax_combine(bv, bidx, ov, oi);
+                    }
+                    if (en4 == 0 && m < p.M) {
+                        p.amax_val[(size_t)m * p.tiles_n + tile_n] = bv;
+                        p.amax_idx[(size_t)m * p.tiles_n + tile_n] = bidx;
+                    }
+                    if (!p.y) continue;
+                }
                 if (m >= p.M || n >= p.N) continue;
                 float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
                 v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
@@ -231,7 +258,7 @@ int linear_bf16_f32(const float* x, const unsigned short* w, const float* scale,
         set_error("linear_bf16: problem too large");
         return ICAP_ERR_LIMIT;
     }
-    GemmBf16Params p{x, w, scale, bias, residual, gate, y, M, N, K, gate ? hw : 1, act, 0};
+    GemmBf16Params p{x, w, scale, bias, residual, gate, y, M, N, K, gate ? hw : 1, act, 0, nullptr, nullptr};
     if (cfg < 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
         if (N > 64 && t128 >= 512) cfg = 0;
@@ -245,6 +272,26 @@ int linear_bf16_f32(const float* x, const unsigned short* w, const float* scale,
         default: set_error("linear_bf16: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
     }
     return launch_status("linear_bf16");
+}
+
+// Linear layer whose epilogue also emits, per output row and 128-column tile, the maximum and its column (first index on
+// ties): part_val / part_idx [M][linear_bf16_argmax_parts(N)]; y (optional) [M][N].  The vocabulary projection of greedy
+// decoding in bf16 compute mode.
+int linear_bf16_argmax_parts(int N) { return (N + 127) / 128; }
+
+int linear_bf16_argmax_f32(const float* x, const unsigned short* w, const float* scale, const float* bias, float* y, float* part_val,
+                           int* part_idx, int M, int K, int N, hipStream_t st) {
+    if (!x || !w || !part_val || !part_idx || M <= 0 || K <= 0 || N <= 0) { set_error("linear_bf16_argmax: bad arguments"); return ICAP_ERR_ARG; }
+    if (K % 8 || N % 4) { set_error("linear_bf16_argmax: K=%d must be a multiple of 8 and N=%d of 4", K, N); return ICAP_ERR_ALIGN; }
+    if (!aligned16(x) || !aligned16(w) || (y && !aligned16(y)) || (scale && !aligned16(scale)) || (bias && !aligned16(bias))) {
+        set_error("linear_bf16_argmax: pointers must be 16-byte aligned");
+        return ICAP_ERR_ALIGN;
+    }
+    GemmBf16Params p{x, w, scale, bias, nullptr, nullptr, y, M, N, K, 1, ACT_NONE, (N + 127) / 128, part_val, part_idx};
+    const long long tiles = (long long)((M + 127) / 128) * p.tiles_n;
+    if (tiles > 0x7fffffffLL) { set_error("linear_bf16_argmax: problem too large"); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+    return launch_status("linear_bf16_argmax");
 }
 
 // fp32 -> bf16 (round to nearest even), n a multiple of 2

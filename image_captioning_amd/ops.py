@@ -334,6 +334,23 @@ def linear_bf16(x, w_bf16, bias=None, scale=None, act=ACT_NONE, residual=None, g
     return out
 
 
+def linear_bf16_argmax(x, w_bf16, bias=None, scale=None, want_logits=False):
+    """bf16-product vocabulary projection with fused arg-max partials -> (part_val [M,P], part_idx [M,P], logits or None)."""
+    M, K = x.shape
+    Nn = w_bf16.shape[0]
+    lib = N.load()
+    P = lib.icap_linear_bf16_argmax_parts(Nn)
+    pv = torch.empty((M, P), device=x.device, dtype=torch.float32)
+    pi = torch.empty((M, P), device=x.device, dtype=torch.int32)
+    logits = torch.empty((M, Nn), device=x.device, dtype=torch.float32) if want_logits else None
+    span = _Span("linear_bf16", (M, K, Nn, False, False))
+    N.check(lib.icap_linear_bf16_argmax_f32(_ck(x, "x"), _ck(w_bf16, "w", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
+                                            _ck(logits, "logits"), _ck(pv, "pv"), _ck(pi, "pi", torch.int32), M, K, Nn, _stream()),
+            "linear_bf16_argmax")
+    span.done()
+    return pv, pi, logits
+
+
 def topk_sample(logits, k=10, seed=0, offset=0, ids_out=None, want_topk=True):
     """softmax -> top-k -> one multinomial draw per row (the reference's generate_caption head).
     logits [rows, V] (rows may be strided) -> (ids [rows] int64, probs [rows, k], idx [rows, k] int32).

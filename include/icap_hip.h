@@ -160,6 +160,13 @@ int icap_linear_bf16_f32(const float* x, const unsigned short* w_bf16, const flo
                          void* stream);
 int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* stream);
 
+/* icap_linear_bf16_f32 (no residual / gate / activation) whose epilogue also writes arg-max partials: per row and
+ * 128-column tile the maximum and its column, part_val / part_idx [M][icap_linear_bf16_argmax_parts(N)], consumed by
+ * icap_next_token_f32; y may be NULL.  The bf16-mode form of icap_linear_argmax_f32 (greedy TransformerTest.py:147-157). */
+int icap_linear_bf16_argmax_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias, float* y,
+                                float* part_val, int* part_idx, int M, int K, int N, void* stream);
+int icap_linear_bf16_argmax_parts(int N);
+
 /* Top-k sampling head: per row softmax(logits[r][0..V)), its k (<= 16) most probable tokens - probs [rows][k] and
  * idx [rows][k], most probable first - and ids[r*ids_stride] = one of them drawn with probability proportional to its
  * softmax probability from the counter-based generator (row r of a call uses uniform(seed, offset + r), so a caller

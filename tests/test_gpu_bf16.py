@@ -92,3 +92,21 @@ def test_fused_expand_dwconv_bf16(bf16_mode, Cin, Cexp, H, W, ks, s, pad):
     assert float((y16.permute(0, 3, 1, 2).cpu() - ref).abs().max()) <= 2e-2 * scale      # stated bf16 tolerance
     assert float((y16 - y32).abs().max()) <= 2e-2 * scale
     torch.testing.assert_close(part.sum(1).cpu() / (ref.shape[2] * ref.shape[3]), y16.mean((1, 2)).cpu(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 512, 6756), (7, 64, 84), (1024, 512, 100)])
+def test_linear_bf16_argmax_partials(bf16_mode, M, K, N):
+    """The arg-max partials of the bf16 vocabulary projection reduce to the row arg-max of its own logits."""
+    ops = bf16_mode
+    g = torch.Generator().manual_seed(M + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    w16 = ops.to_bf16(w.to(D))
+    pv, pi, logits = ops.linear_bf16_argmax(x.to(D), w16, b.to(D), want_logits=True)
+    ref = ops.linear_bf16(x.to(D), w16, b.to(D))
+    torch.testing.assert_close(logits, ref, rtol=0, atol=0)
+    best = pv.argmax(1)
+    ids = pi.gather(1, best[:, None]).squeeze(1).long()
+    assert torch.equal(ids, ref.argmax(1))
+    assert torch.equal(pv.max(1).values, ref.max(1).values)
+    pv2, pi2, none = ops.linear_bf16_argmax(x.to(D), w16, b.to(D))
+    assert none is None and torch.equal(pv2, pv) and torch.equal(pi2, pi)

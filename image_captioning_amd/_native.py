@@ -67,15 +67,15 @@ SIGNATURES = {
     "icap_expand_dwconv_chunks": (_i, [_i] * 6),
     "icap_stem_dwconv_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),
     "icap_stem_dwconv_chunks": (_i, [_i] * 3),
-    "icap_expand_dwconv_bf16_f32": (_i, [_p] * 9 + [_i] * 11 + [_p]),
-    "icap_stem_dwconv_bf16_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),
+    "icap_expand_dwconv_bf16_f32": (_i, [_p] * 8 + [_i, _p] + [_i] * 11 + [_p]),
+    "icap_stem_dwconv_bf16_f32": (_i, [_p] * 8 + [_i, _p] + [_i] * 12 + [_p]),
     "icap_se_gate_f32": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "icap_maxpool2d_f32": (_i, [_p, _p] + [_i] * 9 + [_p]),
     "icap_adaptive_avgpool2d_f32": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "icap_embedding_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "icap_layernorm_f32": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _f, _f, _p]),
     "icap_argmax_rows_f32": (_i, [_p, _i, _p, _i, _i, _i, _p, _p]),
-    "icap_linear_bf16_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "icap_linear_bf16_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "icap_to_bf16_f32": (_i, [_p, _p, _ll, _p]),
     "icap_linear_bf16_argmax_f32": (_i, [_p] * 7 + [_i, _i, _i, _p]),
     "icap_linear_bf16_argmax_parts": (_i, [_i]),

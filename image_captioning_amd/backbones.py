@@ -322,8 +322,10 @@ class EfficientNetB0(nn.Module):
         d0 = blocks[0]
         if d0["expand"] is None and d0["k"] == 3 and d0["stride"] == 1 and not d0["skip"]:
             # the stem's 112x112x32 output feeds only block 0's depthwise convolution: both run in one kernel
+            # (in bf16 mode the fused kernels hand their result to the project convolution as a bf16 tensor)
             h, part = ops.stem_dwconv2d(x, p["stem_w"], *p["stem_sb"], d0["dw_w"], *d0["dw_sb"], stem_pad=(lo, hi, lo, hi),
-                                        pad=(1, 1, 1, 1), want_partial=True)
+                                        pad=(1, 1, 1, 1), want_partial=True,
+                                        out_bf16=ops.bf16_activations_ok(d0["dw_w"].shape[1], d0["proj"][0].shape[0]))
             gate = ops.se_gate(part, h.shape[1] * h.shape[2], *d0["se"])
             x = ops.pointwise_conv(h, d0["proj"][0], d0, "proj16", *d0["proj"][1], gate=gate)
             blocks = blocks[1:]
@@ -338,7 +340,8 @@ class EfficientNetB0(nn.Module):
                                                                        d["k"], d["stride"], pad):
                 # early blocks: the 6x expanded activations stay on chip between the 1x1 and the depthwise convolution
                 h, part = ops.expand_dwconv2d(h, d["expand"][0], *d["expand"][1], d["dw_w"], *d["dw_sb"], ks=d["k"],
-                                              stride=d["stride"], pad=pad, want_partial=True)
+                                              stride=d["stride"], pad=pad, want_partial=True,
+                                              out_bf16=ops.bf16_activations_ok(d["dw_w"].shape[1], d["proj"][0].shape[0]))
             else:
                 if d["expand"] is not None:
                     h = ops.pointwise_conv(h, d["expand"][0], d, "expand16", *d["expand"][1], act=ops.ACT_SWISH)

@@ -27,8 +27,8 @@ int linear_argmax_parts(int);
 int linear_argmax_f32(const float*, const float*, const float*, const float*, float*, float*, int*, int, int, int, hipStream_t);
 int next_token_f32(const float*, const int*, int, long long*, int, const float*, const float*, const float*, const float*, float,
                    float*, int, int, int, hipStream_t);
-int linear_bf16_f32(const float*, const unsigned short*, const float*, const float*, const float*, const float*, int, float*, int, int,
-                    int, int, int, hipStream_t);
+int linear_bf16_f32(const void*, int, const unsigned short*, const float*, const float*, const float*, const float*, int, float*, int,
+                    int, int, int, int, hipStream_t);
 int to_bf16_f32(const float*, unsigned short*, long long, hipStream_t);
 int linear_bf16_argmax_parts(int);
 int linear_bf16_argmax_f32(const float*, const unsigned short*, const float*, const float*, float*, float*, int*, int, int, int, hipStream_t);
@@ -154,9 +154,10 @@ int icap_next_token_f32(const float* part_val, const int* part_idx, int nparts, 
                           (hipStream_t)stream);
 }
 
-int icap_linear_bf16_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias, const float* residual,
-                         const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, void* stream) {
-    return linear_bf16_f32(x, w_bf16, scale, bias, residual, gate, hw, y, M, K, N, act, cfg, (hipStream_t)stream);
+int icap_linear_bf16_f32(const void* x, int x_bf16, const unsigned short* w_bf16, const float* scale, const float* bias,
+                         const float* residual, const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg,
+                         void* stream) {
+    return linear_bf16_f32(x, x_bf16, w_bf16, scale, bias, residual, gate, hw, y, M, K, N, act, cfg, (hipStream_t)stream);
 }
 
 int icap_linear_bf16_argmax_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias, float* y,
@@ -191,10 +192,10 @@ int icap_expand_dwconv_f32(const float* x, const float* w_exp, const float* exp_
 }
 
 int icap_expand_dwconv_bf16_f32(const float* x, const float* w_exp, const float* exp_scale, const float* exp_bias, const float* w_dw,
-                                const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int H, int W, int Cin,
-                                int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
-    return expand_dwconv_f32(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, y, partial, B, H, W, Cin, Cexp, KS, stride,
-                             pad_t, pad_l, Ho, Wo, 1, (hipStream_t)stream);
+                                const float* dw_scale, const float* dw_bias, void* y, int y_bf16, float* partial, int B, int H, int W,
+                                int Cin, int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+    return expand_dwconv_f32(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, (float*)y, partial, B, H, W, Cin, Cexp, KS,
+                             stride, pad_t, pad_l, Ho, Wo, 1 | (y_bf16 ? 2 : 0), (hipStream_t)stream);
 }
 
 int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias, const float* w_dw,
@@ -206,11 +207,11 @@ int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_
 }
 
 int icap_stem_dwconv_bf16_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias, const float* w_dw,
-                              const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int img_h, int img_w,
-                              int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,
+                              const float* dw_scale, const float* dw_bias, void* y, int y_bf16, float* partial, int B, int img_h,
+                              int img_w, int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,
                               void* stream) {
-    return stem_dwconv_f32(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, y, partial, B, img_h, img_w, Hs, Ws, C,
-                           stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, 1, (hipStream_t)stream);
+    return stem_dwconv_f32(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, (float*)y, partial, B, img_h, img_w, Hs, Ws, C,
+                           stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, 1 | (y_bf16 ? 2 : 0), (hipStream_t)stream);
 }
 
 int icap_stem_dwconv_chunks(int Ho, int Wo, int C) { return stem_dwconv_chunks(Ho, Wo, C); }

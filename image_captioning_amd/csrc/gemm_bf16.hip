@@ -38,7 +38,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-template <int BM, int BN, bool GATE, bool AMAX = false>
+// A16: x is a bf16 tensor (the output of a fused kernel run with a bf16 result): its tile goes to LDS as loaded, or
+// through an fp32 multiply when the squeeze-excite gate applies.
+template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) {
     constexpr int BK = GB16_BK, LDK = GB16_LDK;
     constexpr int TM = BM / 2, TN = BN / 2, RM = TM / 32, RN = TN / 32;
@@ -75,6 +77,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
         a_src[i] = p.x + (size_t)(a_ok[i] ? m : 0) * p.K;
         if (GATE) g_src[i] = p.gate + (size_t)((a_ok[i] ? m : 0) / p.hw) * p.K;
     }
+    // bf16 A: staged like W (thread t -> row t/4 + 64 i, eight bf16 at 8 (t%4))
+    constexpr int AP16 = (BM + 63) / 64;
+    const unsigned short* a16_src[A16 ? AP16 : 1];
+    const float* g16_src[(A16 && GATE) ? AP16 : 1];
+    bool a16_ok[A16 ? AP16 : 1];
+    if constexpr (A16) {
+#pragma unroll
+        for (int i = 0; i < AP16; ++i) {
+            const int m = m0 + b_row + 64 * i;
+            a16_ok[i] = (b_row + 64 * i < BM) && m < p.M;
+            a16_src[i] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)(a16_ok[i] ? m : 0) * p.K;
+            if constexpr (GATE) g16_src[i] = p.gate + (size_t)((a16_ok[i] ? m : 0) / p.hw) * p.K;
+        }
+    }
     const unsigned short* b_src[BP];
     bool b_ok[BP];
 #pragma unroll
@@ -86,13 +102,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
 
     float4 ra[AP], rg[GATE ? AP : 1];
     uint4 rb[BP];
+    uint4 ra16[A16 ? AP16 : 1];
+    float4 rg16[(A16 && GATE) ? AP16 : 1][2];
     unsigned okmask = 0;
     // every load is unconditional (clamped address); out-of-range elements are zeroed when the slice goes to LDS
     auto gload = [&](int t) {
         const int ka = t * BK + a_k4, kb = t * BK + b_k8;
         okmask = 0;
+        if constexpr (A16) {
 #pragma unroll
-        for (int i = 0; i < AP; ++i) {
+            for (int i = 0; i < AP16; ++i) {
+                const bool ok = a16_ok[i] && kb < p.K;
+                ra16[i] = *reinterpret_cast<const uint4*>(ok ? a16_src[i] + kb : reinterpret_cast<const unsigned short*>(p.x));
+                if constexpr (GATE) {
+                    rg16[i][0] = *reinterpret_cast<const float4*>(ok ? g16_src[i] + kb : p.gate);
+                    rg16[i][1] = *reinterpret_cast<const float4*>(ok ? g16_src[i] + kb + 4 : p.gate);
+                }
+                okmask |= ok ? (1u << i) : 0u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (A16 ? 0 : AP); ++i) {
             const bool ok = a_ok[i] && ka < p.K;
             ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ka : p.x);
             if (GATE) rg[i] = *reinterpret_cast<const float4*>(ok ? g_src[i] + ka : p.gate);
@@ -106,8 +136,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
         }
     };
     auto lds_store = [&](int buf) {
+        if constexpr (A16) {
 #pragma unroll
-        for (int i = 0; i < AP; ++i) {
+            for (int i = 0; i < AP16; ++i) {
+                if (BM % 64 == 0 || b_row + 64 * i < BM) {
+                    uint4 o = ra16[i];
+                    if constexpr (GATE) {   // bf16 -> fp32 is a 16-bit shift; multiply by the gate, round back
+                        const unsigned w[4] = {o.x, o.y, o.z, o.w};
+                        const float g[8] = {rg16[i][0].x, rg16[i][0].y, rg16[i][0].z, rg16[i][0].w,
+                                            rg16[i][1].x, rg16[i][1].y, rg16[i][1].z, rg16[i][1].w};
+                        unsigned r[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            r[j] = pack_bf16(__uint_as_float(w[j] << 16) * g[2 * j], __uint_as_float(w[j] & 0xffff0000u) * g[2 * j + 1]);
+                        o = make_uint4(r[0], r[1], r[2], r[3]);
+                    }
+                    if (!((okmask >> i) & 1u)) o = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(&As[(buf * BM + b_row + 64 * i) * LDK + b_k8]) = o;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (A16 ? 0 : AP); ++i) {
             float4 v = ra[i];
             if (GATE) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
             uint2 o = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
@@ -237,16 +287,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
 }
 
 template <int BM, int BN>
-static void gb16_launch(GemmBf16Params& p, hipStream_t st) {
+static void gb16_launch(GemmBf16Params& p, bool a16, hipStream_t st) {
     p.tiles_n = (p.N + BN - 1) / BN;
-    const long long tiles = (long long)((p.M + BM - 1) / BM) * p.tiles_n;
-    if (p.gate) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true>), dim3((unsigned)tiles), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)((long long)((p.M + BM - 1) / BM) * p.tiles_n)), block(256);
+    if (a16) {
+        if (p.gate) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true, false, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, true>), grid, block, 0, st, p);
+    } else {
+        if (p.gate) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false>), grid, block, 0, st, p);
+    }
 }
 
-// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles.
-int linear_bf16_f32(const float* x, const unsigned short* w, const float* scale, const float* bias, const float* residual,
+// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles; x_bf16: x points to a bf16 [M][K] tensor.
+int linear_bf16_f32(const void* xv, int x_bf16, const unsigned short* w, const float* scale, const float* bias, const float* residual,
                     const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, hipStream_t st) {
+    const float* x = reinterpret_cast<const float*>(xv);
     if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0 || (gate && hw <= 0)) { set_error("linear_bf16: bad arguments"); return ICAP_ERR_ARG; }
     if (K % 8 || N % 4) { set_error("linear_bf16: K=%d must be a multiple of 8 and N=%d of 4", K, N); return ICAP_ERR_ALIGN; }
     if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (scale && !aligned16(scale)) || (bias && !aligned16(bias)) ||
@@ -266,9 +322,9 @@ int linear_bf16_f32(const float* x, const unsigned short* w, const float* scale,
         else cfg = 2;
     }
     switch (cfg) {
-        case 0: gb16_launch<128, 128>(p, st); break;
-        case 1: gb16_launch<128, 64>(p, st); break;
-        case 2: gb16_launch<64, 64>(p, st); break;
+        case 0: gb16_launch<128, 128>(p, x_bf16 != 0, st); break;
+        case 1: gb16_launch<128, 64>(p, x_bf16 != 0, st); break;
+        case 2: gb16_launch<64, 64>(p, x_bf16 != 0, st); break;
         default: set_error("linear_bf16: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
     }
     return launch_status("linear_bf16");

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     const float* __restrict__ x, const float* __restrict__ we, const float* __restrict__ es, const float* __restrict__ eb,
     const float* __restrict__ wd, const float* __restrict__ dsc, const float* __restrict__ dbi, float* __restrict__ y,
     float* __restrict__ partial, int H, int W, int Cexp, int pad_t, int pad_l, int Ho, int Wo, int tiles_w, int cpg,
-    int img_h, int img_w, int stem_pad_t, int stem_pad_l) {
+    int img_h, int img_w, int stem_pad_t, int stem_pad_l, int out16) {
     static_assert(!STEM || CIN == 40, "the stem patch is 36 values padded to 40");
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS, P = IH * IW;
     constexpr int MB = (P + 31) / 32;          // 32-pixel row blocks
@@ -283,7 +283,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
                     if (wl < TW && ho < Ho && wo < Wo) {
                         float4 u = acc[o];
                         u.x *= sigmoid_fast(u.x); u.y *= sigmoid_fast(u.y); u.z *= sigmoid_fast(u.z); u.w *= sigmoid_fast(u.w);
-                        *reinterpret_cast<float4*>(y + (ybase + (size_t)ho * Wo + wo) * Cexp + c) = u;
+                        const size_t yo = (ybase + (size_t)ho * Wo + wo) * Cexp + c;
+                        if (out16) {   // bf16 output tensor (round to nearest even): half the store traffic
+                            const xd_f32x2 lo = {u.x, u.y}, hi = {u.z, u.w};
+                            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + yo) =
+                                make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, xd_bf16x2)),
+                                           __builtin_bit_cast(unsigned, __builtin_convertvector(hi, xd_bf16x2)));
+                        } else {
+                            *reinterpret_cast<float4*>(y + yo) = u;
+                        }
                         sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
                     }
                 }
@@ -337,6 +345,8 @@ int expand_dwconv_f32(const float* x, const float* we, const float* es, const fl
         set_error("expand_dwconv: bad arguments");
         return ICAP_ERR_ARG;
     }
+    const int out16 = (bf16 >> 1) & 1;     // bf16: bit 0 = bf16 products, bit 1 = bf16 output tensor
+    bf16 &= 1;
     const XdCfg* c = xd_find(Cin, KS, stride);
     if (!c || Cexp <= 0 || Cexp % 4) {
         set_error("expand_dwconv: no fused kernel for Cin=%d, %dx%d stride %d, Cexp=%d", Cin, KS, KS, stride, Cexp);
@@ -365,9 +375,9 @@ int expand_dwconv_f32(const float* x, const float* we, const float* es, const fl
 #define ICAP_XD(CIN_, KS_, S_, TH_, TW_, SW_)                                                                                     \
     do {                                                                                                                          \
         if (bf16) hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_, false, true>), grid, block, 0, st, x, we, es, \
-                                     eb, wd, ds, db, y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0);     \
+                                     eb, wd, ds, db, y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0, out16); \
         else hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_>), grid, block, 0, st, x, we, es, eb, wd, ds, db,  \
-                                y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0);                          \
+                                y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0, out16);                   \
     } while (0)
     if (Cin == 16) ICAP_XD(16, 3, 2, 7, 8, 2);
     else if (Cin == 24 && KS == 3) ICAP_XD(24, 3, 1, 14, 14, 7);
@@ -406,14 +416,16 @@ int stem_dwconv_f32(const float* x, const float* ws, const float* ss, const floa
         return ICAP_ERR_ALIGN;
     }
     if (B > 65535) { set_error("stem_dwconv: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
+    const int out16 = (bf16 >> 1) & 1;     // bf16: bit 0 = bf16 products, bit 1 = bf16 output tensor
+    bf16 &= 1;
     const int tiles_w = (Wo + STEM_TW - 1) / STEM_TW;
     const int ntiles = ((Ho + STEM_TH - 1) / STEM_TH) * tiles_w;
     const int nchunks = (C + XD_CC - 1) / XD_CC;
     const dim3 grid(ntiles, B, 1), block(256);
     if (bf16) hipLaunchKernelGGL((expand_dw_kernel<40, 3, 1, STEM_TH, STEM_TW, 7, true, true>), grid, block, 0, st, x, ws, ss, sb, wd, ds,
-                                 db, y, partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l);
+                                 db, y, partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l, out16);
     else hipLaunchKernelGGL((expand_dw_kernel<40, 3, 1, STEM_TH, STEM_TW, 7, true>), grid, block, 0, st, x, ws, ss, sb, wd, ds, db, y,
-                            partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l);
+                            partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l, out16);
     return launch_status("stem_dwconv");
 }
 

@@ -54,7 +54,14 @@ def pointwise_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=N
         y = linear_bf16(x.view(B * H * W, Cin), w16, bias, scale, act=act,
                         residual=residual.view(B * H * W, Cout) if residual is not None else None, gate=gate, hw=H * W)
         return y.view(B, H, W, Cout)
+    if x.dtype != torch.float32:
+        raise IcapError("pointwise_conv: a bf16 activation needs the bf16 kernel (Cin % 8 == 0, Cout % 4 == 0, bf16 mode)")
     return conv2d(x, w, scale, bias, residual=residual, gate=gate, act=act)
+
+
+def bf16_activations_ok(cin: int, cout: int) -> bool:
+    """True when a [.., cin] activation may be handed to pointwise_conv as bf16 (bf16 mode and a shape its kernel takes)."""
+    return COMPUTE_DTYPE == "bf16" and cin % 8 == 0 and cout % 4 == 0
 
 
 def set_autotune(flag: bool) -> None:
@@ -193,7 +200,8 @@ def expand_dwconv_supported(H, W, Cin, Cexp, ks, stride, pad) -> bool:
                                               Cin, Cexp, ks, stride) > 0
 
 
-def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, ks, stride=1, pad=(0, 0, 0, 0), want_partial=False):
+def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, ks, stride=1, pad=(0, 0, 0, 0), want_partial=False,
+                    out_bf16=False):
     """x [B,H,W,Cin], w_exp [Cexp,1,1,Cin] or [Cexp,Cin], w_dw [ks*ks, Cexp] -> (swish(bn(dw(swish(bn(expand(x)))))), partial)."""
     B, H, W, Cin = x.shape
     Cexp = w_exp.shape[0]
@@ -206,19 +214,26 @@ def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, k
     nch = lib.icap_expand_dwconv_chunks(Ho, Wo, Cin, Cexp, ks, stride)
     if nch <= 0:
         raise IcapError(f"expand_dwconv2d: no fused kernel for Cin={Cin}, {ks}x{ks} stride {stride}")
-    y = torch.empty((B, Ho, Wo, Cexp), device=x.device, dtype=torch.float32)
+    bf16 = COMPUTE_DTYPE == "bf16"
+    if out_bf16 and not bf16:
+        raise IcapError("expand_dwconv2d: a bf16 result needs the bf16 compute mode")
+    ydt = torch.bfloat16 if out_bf16 else torch.float32
+    y = torch.empty((B, Ho, Wo, Cexp), device=x.device, dtype=ydt)
     partial = torch.empty((B, nch, Cexp), device=x.device, dtype=torch.float32) if want_partial else None
-    span = _Span("expand_dwconv2d", (B, H, W, Cin, Cexp, ks, stride, Ho, Wo))
-    entry = lib.icap_expand_dwconv_bf16_f32 if COMPUTE_DTYPE == "bf16" else lib.icap_expand_dwconv_f32
-    N.check(entry(_ck(x, "x"), _ck(w_exp, "w_exp"), _ck(exp_scale, "exp_scale"), _ck(exp_bias, "exp_bias"),
-                                       _ck(w_dw, "w_dw"), _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"), _ck(y, "y"),
-                                       _ck(partial, "partial"), B, H, W, Cin, Cexp, ks, stride, pt, pl, Ho, Wo, _stream()),
-            "expand_dwconv2d")
+    span = _Span("expand_dwconv2d", (B, H, W, Cin, Cexp, ks, stride, Ho, Wo, out_bf16))
+    head = (_ck(x, "x"), _ck(w_exp, "w_exp"), _ck(exp_scale, "exp_scale"), _ck(exp_bias, "exp_bias"), _ck(w_dw, "w_dw"),
+            _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"))
+    tail = (_ck(partial, "partial"), B, H, W, Cin, Cexp, ks, stride, pt, pl, Ho, Wo, _stream())
+    if bf16:
+        N.check(lib.icap_expand_dwconv_bf16_f32(*head, _ck(y, "y", ydt), int(out_bf16), *tail), "expand_dwconv2d")
+    else:
+        N.check(lib.icap_expand_dwconv_f32(*head, _ck(y, "y"), *tail), "expand_dwconv2d")
     span.done()
     return y, partial
 
 
-def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, stem_pad=(0, 1, 0, 1), pad=(1, 1, 1, 1), want_partial=False):
+def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, stem_pad=(0, 1, 0, 1), pad=(1, 1, 1, 1), want_partial=False,
+                  out_bf16=False):
     """x [B,H,W,4] (image, channels padded to 4), w_stem [C,3,3,4], w_dw [9, C] ->
     (swish(bn(dw3x3(swish(bn(conv3x3 stride 2 (x)))))), partial): EfficientNet stem + block 0's depthwise convolution."""
     B, H, W, c4 = x.shape
@@ -230,14 +245,20 @@ def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, 
     Ho = conv_out_size(Hs, 3, 1, pad[0], pad[1])
     Wo = conv_out_size(Ws, 3, 1, pad[2], pad[3])
     lib = N.load()
-    y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    bf16 = COMPUTE_DTYPE == "bf16"
+    if out_bf16 and not bf16:
+        raise IcapError("stem_dwconv2d: a bf16 result needs the bf16 compute mode")
+    ydt = torch.bfloat16 if out_bf16 else torch.float32
+    y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=ydt)
     partial = torch.empty((B, lib.icap_stem_dwconv_chunks(Ho, Wo, Cc), Cc), device=x.device, dtype=torch.float32) if want_partial else None
-    span = _Span("stem_dwconv2d", (B, H, W, Cc, Hs, Ws, Ho, Wo))
-    entry = lib.icap_stem_dwconv_bf16_f32 if COMPUTE_DTYPE == "bf16" else lib.icap_stem_dwconv_f32
-    N.check(entry(_ck(x, "x"), _ck(w_stem, "w_stem"), _ck(stem_scale, "stem_scale"), _ck(stem_bias, "stem_bias"),
-                                     _ck(w_dw, "w_dw"), _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"), _ck(y, "y"),
-                                     _ck(partial, "partial"), B, H, W, Hs, Ws, Cc, stem_pad[0], stem_pad[2], pad[0], pad[2], Ho, Wo,
-                                     _stream()), "stem_dwconv2d")
+    span = _Span("stem_dwconv2d", (B, H, W, Cc, Hs, Ws, Ho, Wo, out_bf16))
+    head = (_ck(x, "x"), _ck(w_stem, "w_stem"), _ck(stem_scale, "stem_scale"), _ck(stem_bias, "stem_bias"), _ck(w_dw, "w_dw"),
+            _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"))
+    tail = (_ck(partial, "partial"), B, H, W, Hs, Ws, Cc, stem_pad[0], stem_pad[2], pad[0], pad[2], Ho, Wo, _stream())
+    if bf16:
+        N.check(lib.icap_stem_dwconv_bf16_f32(*head, _ck(y, "y", ydt), int(out_bf16), *tail), "stem_dwconv2d")
+    else:
+        N.check(lib.icap_stem_dwconv_f32(*head, _ck(y, "y"), *tail), "stem_dwconv2d")
     span.done()
     return y, partial
 
@@ -315,7 +336,7 @@ def to_bf16(w: torch.Tensor) -> torch.Tensor:
 
 def linear_bf16(x, w_bf16, bias=None, scale=None, act=ACT_NONE, residual=None, gate=None, hw=1, out=None, cfg=-1):
     """y[M,N] = act((x[M,K] (* gate[m // hw]) @ w[N,K]^T) * scale + bias (+ residual)) with bf16 products, fp32
-    accumulation and fp32 tensors in memory; w_bf16 from to_bf16()."""
+    accumulation; w_bf16 from to_bf16(); x fp32 or bf16 (the bf16 result of a fused kernel), everything else fp32."""
     M, K = x.shape
     Nn, K2 = w_bf16.shape[0], w_bf16.numel() // w_bf16.shape[0]
     if K != K2 or w_bf16.dtype != torch.bfloat16:
@@ -326,8 +347,10 @@ def linear_bf16(x, w_bf16, bias=None, scale=None, act=ACT_NONE, residual=None, g
         raise IcapError("linear_bf16: residual has the wrong size")
     if gate is not None and (gate.shape[-1] != K or gate.shape[0] * hw != M):
         raise IcapError("linear_bf16: gate must be [M // hw, K]")
-    span = _Span("linear_bf16", (M, K, Nn, residual is not None, gate is not None))
-    N.check(N.load().icap_linear_bf16_f32(_ck(x, "x"), _ck(w_bf16, "w", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
+    x16 = x.dtype == torch.bfloat16
+    span = _Span("linear_bf16", (M, K, Nn, residual is not None, gate is not None, x16))
+    N.check(N.load().icap_linear_bf16_f32(_ck(x, "x", torch.bfloat16 if x16 else torch.float32), int(x16),
+                                          _ck(w_bf16, "w", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
                                           _ck(residual, "residual"), _ck(gate, "gate"), hw, _ck(out, "out"), M, K, Nn, act, cfg,
                                           _stream()), "linear_bf16")
     span.done()

@@ -105,16 +105,17 @@ int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_
 int icap_stem_dwconv_chunks(int Ho, int Wo, int C);
 
 /* The two fused kernels with bf16 products in their first (expand / stem) convolution - operands rounded to bf16 in
- * registers, fp32 accumulation on v_mfma_f32_32x32x16_bf16; the depthwise stage and every tensor in memory stay fp32.
- * Same arguments and layouts as the fp32 forms above. */
+ * registers, fp32 accumulation on v_mfma_f32_32x32x16_bf16; the depthwise stage computes in fp32.  y is fp32
+ * (y_bf16 = 0) or a bf16 tensor of the same shape (y_bf16 = 1, round to nearest even; the squeeze-excite partial sums
+ * are taken before the rounding).  Otherwise the arguments and layouts of the fp32 forms above. */
 int icap_expand_dwconv_bf16_f32(const float* x, const float* w_exp, const float* exp_scale, const float* exp_bias,
-                                const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial,
-                                int B, int H, int W, int Cin, int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho,
-                                int Wo, void* stream);
+                                const float* w_dw, const float* dw_scale, const float* dw_bias, void* y, int y_bf16,
+                                float* partial, int B, int H, int W, int Cin, int Cexp, int KS, int stride, int pad_t,
+                                int pad_l, int Ho, int Wo, void* stream);
 int icap_stem_dwconv_bf16_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias,
-                              const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial,
-                              int B, int img_h, int img_w, int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t,
-                              int pad_l, int Ho, int Wo, void* stream);
+                              const float* w_dw, const float* dw_scale, const float* dw_bias, void* y, int y_bf16,
+                              float* partial, int B, int img_h, int img_w, int Hs, int Ws, int C, int stem_pad_t,
+                              int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo, void* stream);
 
 /* Squeeze-excite gate: gate[b][c] = sigmoid(We . swish(Wr . mean_hw(x) + br) + be),
  * from the chunk sums written by icap_dwconv2d_f32.  wr [S][C]; we [S][C] (the expand weight TRANSPOSED).
@@ -151,11 +152,12 @@ int icap_argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_st
 
 /* bf16-compute form of a Linear layer / 1x1 convolution (fp32 tensors in memory, bf16 weights, fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16):  y[M][N] = act((x[M][K] (* gate[m / hw][k]) @ w^T) * scale[n] + bias[n] (+ residual[m][n])),
- * w_bf16 [N][K] as produced by icap_to_bf16_f32 (round to nearest even).  K % 8 == 0, N % 4 == 0.  cfg -1 picks the
+ * w_bf16 [N][K] as produced by icap_to_bf16_f32 (round to nearest even); x is fp32, or bf16 when x_bf16 = 1 (the bf16
+ * result of a fused kernel).  K % 8 == 0, N % 4 == 0.  cfg -1 picks the
  * tile shape (0: 128x128, 1: 128x64, 2: 64x64).  Same layers as icap_conv2d_f32 with KH = KW = 1 - MBConv `_expand_conv`,
  * `_project_conv`, `_conv_head` (transformer_word_level.py:13) and every nn.Linear of the decoders - at the precision
  * north-star configuration names for the accelerated path. */
-int icap_linear_bf16_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias,
+int icap_linear_bf16_f32(const void* x, int x_bf16, const unsigned short* w_bf16, const float* scale, const float* bias,
                          const float* residual, const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg,
                          void* stream);
 int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* stream);

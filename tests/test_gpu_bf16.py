@@ -92,6 +92,50 @@ def test_fused_expand_dwconv_bf16(bf16_mode, Cin, Cexp, H, W, ks, s, pad):
     assert float((y16.permute(0, 3, 1, 2).cpu() - ref).abs().max()) <= 2e-2 * scale      # stated bf16 tolerance
     assert float((y16 - y32).abs().max()) <= 2e-2 * scale
     torch.testing.assert_close(part.sum(1).cpu() / (ref.shape[2] * ref.shape[3]), y16.mean((1, 2)).cpu(), rtol=1e-4, atol=1e-5)
+    # bf16 result tensor: the same values rounded to nearest even on the store; the SE partial sums stay those of the fp32 values
+    yb, partb = ops.expand_dwconv2d(*args, ks=ks, stride=s, pad=pad, want_partial=True, out_bf16=True)
+    assert yb.dtype == torch.bfloat16 and torch.equal(yb, y16.to(torch.bfloat16)) and torch.equal(partb, part)
+    ops.set_compute_dtype("f32")
+    with pytest.raises(ops.IcapError):
+        ops.expand_dwconv2d(*args, ks=ks, stride=s, pad=pad, out_bf16=True)
+
+
+def test_fused_stem_dwconv_bf16_result(bf16_mode):
+    ops = bf16_mode
+    g = lambda seed: torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 45, 51, 4, generator=g(1)).to(D)
+    x[..., 3] = 0
+    ws = (torch.randn(32, 3, 3, 4, generator=g(2)) * 0.2).to(D)
+    ws[..., 3] = 0
+    ss, sb = (torch.rand(32, generator=g(3)) + 0.5).to(D), (torch.randn(32, generator=g(4)) * 0.3).to(D)
+    wd = (torch.randn(9, 32, generator=g(5)) / 3).to(D)
+    dsc, dbi = (torch.rand(32, generator=g(6)) + 0.5).to(D), (torch.randn(32, generator=g(7)) * 0.1).to(D)
+    ops.set_compute_dtype("bf16")
+    y, part = ops.stem_dwconv2d(x, ws, ss, sb, wd, dsc, dbi, want_partial=True)
+    yb, partb = ops.stem_dwconv2d(x, ws, ss, sb, wd, dsc, dbi, want_partial=True, out_bf16=True)
+    assert yb.dtype == torch.bfloat16 and torch.equal(yb, y.to(torch.bfloat16)) and torch.equal(partb, part)
+
+
+@pytest.mark.parametrize("M,K,N,hw", [(2 * 49, 96, 24, 49), (300, 240, 40, 100), (37, 32, 16, 37), (513, 144, 132, 171)])
+def test_linear_bf16_takes_bf16_activations(bf16_mode, M, K, N, hw):
+    """A bf16 activation tensor gives exactly what its fp32 copy gives without a gate (bf16 -> fp32 -> bf16 is the identity);
+    with an SE gate the product gate*x is rounded once more, so it is checked against torch on that rounded product."""
+    ops = bf16_mode
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(D).to(torch.bfloat16)
+    w16 = ops.to_bf16((torch.randn(N, K, generator=g) * K ** -0.5).to(D))
+    b, sc = torch.randn(N, generator=g).to(D), (torch.rand(N, generator=g) + 0.5).to(D)
+    res = torch.randn(M, N, generator=g).to(D)
+    y16 = ops.linear_bf16(x, w16, b, sc, residual=res, act=ops.ACT_SWISH)
+    y32 = ops.linear_bf16(x.float(), w16, b, sc, residual=res, act=ops.ACT_SWISH)
+    assert torch.equal(y16, y32)
+    gate = torch.rand(M // hw, K, generator=g).to(D)
+    yg = ops.linear_bf16(x, w16, b, sc, gate=gate, hw=hw)
+    xg = (x.float().view(M // hw, hw, K) * gate[:, None, :]).to(torch.bfloat16).float().view(M, K)
+    ref = (xg.double() @ w16.float().double().t()) * sc.double() + b.double()
+    torch.testing.assert_close(yg, ref.float(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(ops.IcapError):                                  # the fp32 kernels do not take bf16 tensors
+        ops.conv2d(x.view(1, 1, M, K), torch.randn(N, 1, 1, K, device=D))
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 512, 6756), (7, 64, 84), (1024, 512, 100)])

@@ -34,6 +34,9 @@ int linear_bf16_argmax_parts(int);
 int linear_bf16_argmax_f32(const float*, const unsigned short*, const float*, const float*, float*, float*, int*, int, int, int, hipStream_t);
 int topk_sample_f32(const float*, int, int, int, int, unsigned long long, unsigned long long, float*, int*, long long*, int, hipStream_t);
 int nchw_to_nhwc_pad_f32(const float*, float*, int, int, int, int, int, hipStream_t);
+long long resize_normalize_ws_bytes(int, int, int);
+int resize_normalize_u8_f32(const unsigned char*, int, int, int, const int*, const int*, int, const int*, const int*, int, int, int,
+                            const float*, unsigned*, float*, int, hipStream_t);
 int dwconv2d_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
                  int, int, int, int, int, hipStream_t);
 int dwconv_chunks(int, int, int, int, int);
@@ -574,6 +577,15 @@ int icap_dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, in
     return dwconv_bwd_weight_f32(dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, dw, ws, (hipStream_t)stream);
 }
 long long icap_dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K) { return dwconv_bwd_weight_ws_floats(B, Ho, Wo, C, K); }
+
+long long icap_resize_normalize_ws_bytes(int B, int H, int Wo) { return resize_normalize_ws_bytes(B, H, Wo); }
+
+int icap_resize_normalize_u8_f32(const unsigned char* src, int B, int H, int W, const int* kx, const int* bx, int ksx, const int* ky,
+                                 const int* by, int ksy, int Ho, int Wo, const float* mean_std, void* tmp, float* out, int layout,
+                                 void* stream) {
+    return resize_normalize_u8_f32(src, B, H, W, kx, bx, ksx, ky, by, ksy, Ho, Wo, mean_std, (unsigned*)tmp, out, layout,
+                                   (hipStream_t)stream);
+}
 
 int icap_transpose_f32(const float* src, int rows, int cols, int ld_src, float* dst, void* stream) {
     return transpose_f32(src, rows, cols, ld_src, dst, (hipStream_t)stream);

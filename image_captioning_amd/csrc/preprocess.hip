@@ -1,0 +1,109 @@
+// Image preprocessing on the device: the deterministic tail of the reference's image transform
+// (data.py:170-172, datachar.py:129-131: Resize((224, 224)) on a PIL image, ToTensor, Normalize), bit-exact.
+//
+// torchvision resizes a PIL image with Pillow's BILINEAR resampler, which is not a two-tap interpolation: it is a
+// separable triangle filter whose support grows with the down-scaling factor, evaluated in 22-bit fixed point, with the
+// horizontally resized image rounded to 8 bits before the vertical pass.  The two passes are kept as two kernels with an
+// 8-bit intermediate, because that rounding is part of the result.  The filter taps (integers) and tap ranges depend
+// only on (input size, output size); the caller computes them once per size on the host and passes them in.
+//
+//   pass 1  tmp[b][y][xo]   = clip8((2^21 + sum_t src[b][y][bx[xo][0] + t][c] * kx[xo][t]) >> 22)   for c in r, g, b
+//   pass 2  v               = clip8((2^21 + sum_t tmp[b][by[yo][0] + t][xo][c] * ky[yo][t]) >> 22)
+//           out[b][c][yo][xo] = (v / 255 - mean[c]) / std[c]                                          (fp32, IEEE division)
+//
+// tmp packs r, g, b into one 32-bit word per pixel so the vertical pass reads one word per tap.
+#include "common.hpp"
+
+namespace icap {
+
+constexpr int RS_PREC = 22;   // Pillow: PRECISION_BITS = 32 - 8 - 2
+
+__device__ __forceinline__ unsigned rs_clip8(int v) {
+    v >>= RS_PREC;            // arithmetic shift, as Pillow's lookup index
+    return (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// one thread per (image row, output column); a workgroup covers 256 consecutive columns*rows of one image
+__global__ __launch_bounds__(256) void resize_h_kernel(const unsigned char* __restrict__ src, const int* __restrict__ kx,
+                                                       const int* __restrict__ bx, unsigned* __restrict__ tmp, int W, int Wo,
+                                                       int ksx, long long rows) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * Wo) return;
+    const long long row = i / Wo;
+    const int xo = (int)(i - row * Wo);
+    int x0 = bx[2 * xo], n = bx[2 * xo + 1];
+    n = n < 0 ? 0 : (n > ksx ? ksx : (n > W ? W : n));      // a malformed table must not turn into a wild read
+    x0 = x0 < 0 ? 0 : (x0 > W - n ? W - n : x0);
+    const unsigned char* s = src + (row * W + x0) * 3;
+    const int* k = kx + (long long)xo * ksx;
+    int r = 1 << (RS_PREC - 1), g = r, b = r;
+    for (int t = 0; t < n; ++t) {
+        const int w = k[t];
+        r += (int)s[3 * t] * w;
+        g += (int)s[3 * t + 1] * w;
+        b += (int)s[3 * t + 2] * w;
+    }
+    tmp[i] = rs_clip8(r) | (rs_clip8(g) << 8) | (rs_clip8(b) << 16);
+}
+
+// one thread per output pixel; layout 0: out [B][3][Ho][Wo] (the reference's tensor), 1: out [B][Ho][Wo][4] with a zero
+// fourth channel (the layout the encoder's first convolution reads)
+__global__ __launch_bounds__(256) void resize_v_normalize_kernel(const unsigned* __restrict__ tmp, const int* __restrict__ ky,
+                                                                 const int* __restrict__ by, const float* __restrict__ mean_std,
+                                                                 float* __restrict__ out, int H, int Ho, int Wo, int ksy,
+                                                                 int layout, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long bimg = i / ((long long)Ho * Wo);
+    const int rem = (int)(i - bimg * Ho * Wo);
+    const int yo = rem / Wo, xo = rem - yo * Wo;
+    int y0 = by[2 * yo], n = by[2 * yo + 1];
+    n = n < 0 ? 0 : (n > ksy ? ksy : (n > H ? H : n));
+    y0 = y0 < 0 ? 0 : (y0 > H - n ? H - n : y0);
+    const unsigned* s = tmp + ((bimg * H + y0) * Wo + xo);
+    const int* k = ky + (long long)yo * ksy;
+    int r = 1 << (RS_PREC - 1), g = r, b = r;
+    for (int t = 0; t < n; ++t) {
+        const unsigned p = s[(long long)t * Wo];
+        const int w = k[t];
+        r += (int)(p & 255u) * w;
+        g += (int)((p >> 8) & 255u) * w;
+        b += (int)((p >> 16) & 255u) * w;
+    }
+    const float fr = ((float)rs_clip8(r) / 255.0f - mean_std[0]) / mean_std[3];
+    const float fg = ((float)rs_clip8(g) / 255.0f - mean_std[1]) / mean_std[4];
+    const float fb = ((float)rs_clip8(b) / 255.0f - mean_std[2]) / mean_std[5];
+    if (layout == 0) {
+        const long long plane = (long long)Ho * Wo;
+        float* o = out + bimg * 3 * plane + rem;
+        o[0] = fr;
+        o[plane] = fg;
+        o[2 * plane] = fb;
+    } else {
+        reinterpret_cast<float4*>(out)[i] = make_float4(fr, fg, fb, 0.f);
+    }
+}
+
+long long resize_normalize_ws_bytes(int B, int H, int Wo) { return (long long)B * H * Wo * 4; }
+
+// src [B][H][W][3] uint8; kx [Wo][ksx], bx [Wo][2], ky [Ho][ksy], by [Ho][2] int32; mean_std: 3 means then 3 stds;
+// tmp: resize_normalize_ws_bytes(B, H, Wo) bytes.  Tap ranges are clamped to the image in the kernels.
+int resize_normalize_u8_f32(const unsigned char* src, int B, int H, int W, const int* kx, const int* bx, int ksx, const int* ky,
+                            const int* by, int ksy, int Ho, int Wo, const float* mean_std, unsigned* tmp, float* out, int layout,
+                            hipStream_t st) {
+    if (!src || !kx || !bx || !ky || !by || !mean_std || !tmp || !out || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 ||
+        ksx <= 0 || ksy <= 0 || (layout != 0 && layout != 1)) {
+        set_error("resize_normalize: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (layout == 1 && !aligned16(out)) { set_error("resize_normalize: out must be 16-byte aligned"); return ICAP_ERR_ALIGN; }
+    const long long n1 = (long long)B * H * Wo, n2 = (long long)B * Ho * Wo;
+    const long long g1 = (n1 + 255) / 256, g2 = (n2 + 255) / 256;
+    if (g1 > 0x7fffffffLL || g2 > 0x7fffffffLL) { set_error("resize_normalize: too large"); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)g1), dim3(256), 0, st, src, kx, bx, tmp, W, Wo, ksx, (long long)B * H);
+    hipLaunchKernelGGL(resize_v_normalize_kernel, dim3((unsigned)g2), dim3(256), 0, st, tmp, ky, by, mean_std, out, H, Ho, Wo, ksy,
+                       layout, n2);
+    return launch_status("resize_normalize");
+}
+
+}  // namespace icap

@@ -439,6 +439,19 @@ long long icap_dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K);
  * dX = dY W (the backward of every nn.Linear / Conv2d on the path, e.g. transformer_word_level_bahdnau.py:188-196). */
 int icap_transpose_f32(const float* src, int rows, int cols, int ld_src, float* dst, void* stream);
 
+/* Deterministic tail of the image transform (data.py:170-172, datachar.py:129-131: Resize((224, 224)) of a PIL image =
+ * Pillow's BILINEAR resampler - separable triangle filter, 22-bit fixed-point taps, 8-bit intermediate after the
+ * horizontal pass - then ToTensor and Normalize), bit-exact.  src [B][H][W][3] uint8 (decoded RGB, all B images of one
+ * size); kx [Wo][ksx] / ky [Ho][ksy] int32 filter taps and bx [Wo][2] / by [Ho][2] (first input index, tap count) as
+ * Pillow's precompute_coeffs + normalize_coeffs_8bpc give them for (W -> Wo) and (H -> Ho); mean_std: 3 means, 3 stds;
+ * tmp: icap_resize_normalize_ws_bytes(B, H, Wo) bytes; out fp32, layout 0 = [B][3][Ho][Wo] (the reference's tensor),
+ * 1 = [B][Ho][Wo][4] with a zero fourth channel.  The random flip / rotation / contrast jitter in front of the resize
+ * (data.py:167-169) are not part of this call. */
+long long icap_resize_normalize_ws_bytes(int B, int H, int Wo);
+int icap_resize_normalize_u8_f32(const unsigned char* src, int B, int H, int W, const int* kx, const int* bx, int ksx,
+                                 const int* ky, const int* by, int ksy, int Ho, int Wo, const float* mean_std, void* tmp,
+                                 float* out, int layout, void* stream);
+
 /* col[m][(r*KW+q)*C + c] = x[b, ho*S-pad_t+r, wo*S-pad_l+q, c]: patches of the stem convolution's input, so that
  * its weight gradient is one icap_gemm_bwd_f32 (a_kmajor = 1) call. */
 int icap_im2col_f32(const float* x, int B, int H, int W, int C, int KH, int KW, int S, int pad_t, int pad_l, int Ho,

@@ -1,0 +1,129 @@
+"""GPU: the resize + normalise kernel against the numpy restatement of Pillow's resampler (bit-exact: integer pixels and
+IEEE fp32 normalisation), the collate functions built on it, and the evaluation helpers."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from image_captioning_amd import data as d, datachar as dc, evaluation, preprocess, training
+from oracle import pil_resize_ref as R
+from oracle.make_resize_fixture import RANDOM_CASES, random_case
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+D = "cuda:0"
+MEAN = np.array(preprocess.IMAGENET_MEAN, np.float32).reshape(3, 1, 1)
+STD = np.array(preprocess.IMAGENET_STD, np.float32).reshape(3, 1, 1)
+
+
+def to_u8(t):
+    """Invert the normalisation exactly enough to recover the 8-bit pixel."""
+    x = t.cpu().numpy() * STD + MEAN
+    return np.rint(x * 255.0).astype(np.uint8).transpose(1, 2, 0)
+
+
+def test_kernel_reproduces_the_fixture_bit_for_bit():
+    g = H.load("pil_resize")
+    for name in ("photo_169x274", "photo_240x240"):
+        y = preprocess.resize_normalize(g[f"{name}_in"])
+        assert y.shape == (1, 3, 224, 224) and y.dtype == torch.float32
+        assert np.array_equal(y[0].cpu().numpy(), R.to_tensor_normalize(g[f"{name}_out"]))
+    assert np.array_equal(preprocess.resize_normalize(g["photo_169x274_in"])[0].cpu().numpy(), g["photo_169x274_norm"])
+    for h, w in RANDOM_CASES:                                      # up-scaling, identity pass, 9 and 39 taps, width 1
+        y = preprocess.resize_normalize(random_case(h, w))
+        u8 = to_u8(y[0])
+        assert zlib.crc32(u8.tobytes()) == int(g[f"rand_{h}x{w}_crc"])
+
+
+@pytest.mark.parametrize("B,h,w,size", [(5, 169, 274, 224), (3, 61, 47, 256), (2, 512, 300, 224), (1, 224, 224, 224)])
+def test_kernel_matches_the_oracle_batched_and_in_both_layouts(B, h, w, size):
+    rng = np.random.default_rng(B * 1000 + h)
+    a = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+    ref = np.stack([R.to_tensor_normalize(R.resize_bilinear_u8(a[i], size)) for i in range(B)])
+    y = preprocess.resize_normalize(torch.from_numpy(a).to(D), size=size)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    y4 = preprocess.resize_normalize(a, size=size, layout="nhwc4")
+    assert y4.shape == (B, size, size, 4) and not y4[..., 3].any()
+    assert np.array_equal(y4[..., :3].permute(0, 3, 1, 2).cpu().numpy(), ref)
+    with pytest.raises(preprocess.N.IcapError):
+        preprocess.resize_normalize(a.astype(np.float32))
+    with pytest.raises(preprocess.N.IcapError):
+        preprocess.resize_normalize(a, layout="nchw4")
+
+
+def test_same_result_as_the_host_route_on_the_food_photos():
+    """The committed 224x224 photos: resizing a 224x224 image is the identity, so the kernel output must equal the
+    host normalisation of the same pixels (the tensor every encoder parity test feeds)."""
+    u8 = H.load("food_test_u8")["images"]
+    y = preprocess.resize_normalize(u8)
+    assert np.array_equal(y.cpu().numpy(), np.stack([R.to_tensor_normalize(u8[i]) for i in range(len(u8))]))
+    torch.testing.assert_close(y.cpu(), preprocess.to_model_input(u8), rtol=0, atol=0)
+
+
+def test_collate_groups_ragged_images_and_pads_captions():
+    rng = np.random.default_rng(3)
+    sizes = [(40, 50), (33, 21), (40, 50), (224, 224)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    caps = [torch.tensor([2, 5, 3]), torch.tensor([2, 5, 6, 7, 3]), torch.tensor([2, 3]), torch.tensor([2, 9, 9, 3])]
+    x, c = d.collate_fn(list(zip(imgs, caps)))
+    assert x.shape == (4, 3, 224, 224) and x.is_cuda and c.shape == (4, 5) and c[0].tolist() == [2, 5, 3, 0, 0]
+    for i, im in enumerate(imgs):
+        assert np.array_equal(x[i].cpu().numpy(), R.to_tensor_normalize(R.resize_bilinear_u8(im)))
+    cc = [torch.full((58,), 2, dtype=torch.long)] * 4
+    x2, c2 = dc.collate_fn(list(zip(imgs, cc)))
+    assert torch.equal(x2, x) and c2.shape == (4, 58)
+    batches = list(d.iterate_batches(list(zip(imgs, caps)), batch_size=3))
+    assert [b[0].shape[0] for b in batches] == [3, 1]
+    halves = [list(d.iterate_batches(list(zip(imgs, caps)), batch_size=1, rank=r, world=2)) for r in (0, 1)]
+    assert len(halves[0]) == 2 and len(halves[1]) == 2
+
+
+def test_accuracy_and_bleu_helpers_match_the_reference_values():
+    g = H.load("losses")
+    pred = torch.from_numpy(g["pred"]).to(D)
+    tgt = torch.from_numpy(g["tgt"]).to(D)
+    full = torch.cat([pred, pred[:, :1]], 1).contiguous()
+    assert d.compute_accuracy(full, tgt, 0) == pytest.approx(float(g["compute_acc_pad0"]), abs=1e-6)
+    assert float(d.compute_loss(pred, tgt, 0)) == pytest.approx(float(g["compute_loss_pad0"]), rel=1e-5)
+    idx2word = {i: f"w{i}" for i in range(97)}
+    idx2word[0] = "<PAD>"
+    scores = d.compute_bleu(full, tgt, idx2word, {"<PAD>": 0})
+    ids = g["pred"][0].argmax(-1).tolist() + [int(g["pred"][0, 0].argmax())]
+    want = d.sentence_bleu([[idx2word[i] for i in g["tgt"][0].tolist() if i != 0]], [idx2word[i] for i in ids], weights=(1, 0, 0, 0))
+    assert set(scores) == {"bleu_1", "bleu_2", "bleu_3", "bleu_4"} and scores["bleu_1"] == pytest.approx(want)
+
+
+def test_evaluate_model_harness():
+    """Loss / accuracy / BLEU of evaluate_model on a small Bahdanau model against the same quantities computed with torch
+    on the model's own logits."""
+    import torch.nn.functional as F
+    dims = H.load("bahdanau_small")["dims"]
+    V = int(dims[4])
+    model = H.bah_model(dims).to(D)
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for B in (3, 2):
+        caps = torch.randint(4, V, (B, 7), generator=g)
+        caps[:, 0] = 2
+        caps[0, 5:] = 0
+        batches.append((torch.randn(B, int(dims[1]), generator=g), caps))
+    idx2word = {i: f"w{i}" for i in range(V)}
+    loss_fn = training.CrossEntropyLoss(ignore_index=0)
+    loss, acc, bleu = evaluation.evaluate_model(model, batches, D, idx2word, None, loss_fn, 0)
+    want_loss, want_acc, b1 = [], [], []
+    with torch.no_grad():
+        for x, caps in batches:
+            out = model(x.to(D), caps[:, :-1].contiguous().to(D)).cpu()
+            tgt = caps[:, 1:]
+            want_loss.append(float(F.cross_entropy(out.reshape(-1, V), tgt.reshape(-1), ignore_index=0)))
+            ids = out.argmax(-1)
+            m = (tgt != 0).float()
+            want_acc.append(float(((ids == tgt) * m).sum() / m.sum()))
+            for i in range(len(caps)):
+                b1.append(d.sentence_bleu([[idx2word[t] for t in tgt[i].tolist() if t != 0]], [idx2word[t] for t in ids[i].tolist()],
+                                          weights=[1.0]))
+    assert loss == pytest.approx(np.mean(want_loss), rel=1e-5) and acc == pytest.approx(np.mean(want_acc), abs=1e-6)
+    assert bleu["BLEU-1"] == pytest.approx(np.mean(b1)) and set(bleu) == {"BLEU-1", "BLEU-2", "BLEU-3", "BLEU-4"}
+    with pytest.raises(ValueError):
+        evaluation.evaluate_model(model, [], D, idx2word, None, loss_fn, 0)

@@ -15,7 +15,9 @@ A "step" is one pass of the hot path over one batch of --batch images already re
 NCHW fp32 images -> encoder features -> 20 greedy tokens per image (every image decoded as its own
 batch of one, the reference's generate_caption semantics).  Inference shards by image: each rank
 captions its own images and no data-path collective exists, so scaling is weak.  Rank 0 prints ONE
-JSON line (metric, value, roofline of the dominant kernel, CPU baseline).
+JSON line (metric, value, roofline of the dominant kernel, CPU baseline).  After the timed region the
+line collects two secondary measurements on the same ranks: "bf16_mode" (the same captioning step with
+bf16 products) and "train" (the --mode train step, data-parallel when N > 1).
 """
 from __future__ import annotations
 
@@ -23,6 +25,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -46,6 +49,9 @@ def parse():
                     help="compute dtype of the captioning GEMMs: f32 (default, the reference's), or bf16 products with fp32 "
                          "accumulation and fp32 tensors in memory (captioning mode only)")
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the secondary bf16-mode measurement")
+    ap.add_argument("--no-train-mode", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--train-deadline", type=float, default=240.0,
+                    help="seconds the secondary training measurement may take before the line is printed without it")
     ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 1024 captioning, 256 training)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,6 +117,91 @@ WORK = {"linear_bf16": lambda s: linear_bf16_work(s), "stem_dwconv2d": stem_dw_w
         "dwconv_bwd_weight": lambda s: (2.0 * s[0] * s[6] * s[7] * s[3] * s[4] * s[4], 4.0 * s[3] * s[0] * (s[1] * s[2] + s[6] * s[7]))}
 
 
+TRAIN_WORKLOAD = ("transformer_word_level_bahdnau: teacher-forced training step (EfficientNet-B0 train mode + encoder block + "
+                  "Bahdanau LSTMCell decoder, compute_loss, backward, AdamW), fp32 (BASELINE configs[2] names bf16: not built yet)")
+
+
+def build_train_step(torch, dev, rank, B):
+    """The Bahdanau captioner in train mode on `dev` with its Trainer (data-parallel when a process group is up) and one
+    synthetic batch -> (model, step)."""
+    from image_captioning_amd import transformer_word_level_bahdnau as bah
+    from image_captioning_amd._bah_train import DropoutState
+    from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images
+    from image_captioning_amd.training import Trainer
+    pool = synthetic_images(min(B, 32), seed=1234 + rank)
+    images = pool.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
+    model = bah.build_model(VOCAB, dropout=0.3)                       # transformer_word_level_bahdnau.py:171,183-188
+    model.load_state_dict(seeded_state_dict(model, seed=52))
+    model = model.to(dev)
+    DropoutState.manual_seed(1000 + rank)                             # dropout differs per rank, weights do not
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-5)              # :191
+    caps = synthetic_captions(B, CAPTION_LEN, VOCAB, 2, 3, 0, seed=77 + rank).to(dev)
+
+    def step():
+        return trainer.step(images, caps, 0)
+
+    return model, step
+
+
+def train_parallelism(model, world):
+    if world == 1:
+        return "single GPU, no collective"
+    return f"data-parallel x{world}, bucketed all-reduce of {sum(p.numel() for p in model.parameters()) * 4 / 1e6:.1f} MB of gradients"
+
+
+def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
+    """The second half of the metric, measured after the contract's timed region on the same ranks: K training steps
+    between barriers, max over ranks -> the "train" object of the JSON line."""
+    model, step = build_train_step(torch, dev, rank, B)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ops.set_autotune(True)
+    step()
+    torch.cuda.synchronize()
+    ops.set_autotune(False)
+    for _ in range(2):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": 3,
+            "images_per_step_per_gpu": B, "dtype": "f32", "scaling": "weak", "loss_last_step": float(loss),
+            "workload": TRAIN_WORKLOAD, "parallelism": train_parallelism(model, world)}
+
+
+def with_deadline(seconds, on_timeout, fn):
+    """fn() unless it takes longer than `seconds`: then on_timeout() runs on a timer thread and the process ends there
+    (a rank stuck in a collective cannot be interrupted any other way)."""
+    done = threading.Event()
+
+    def fire():
+        if not done.is_set():
+            try:
+                on_timeout()
+            finally:
+                os._exit(0)
+
+    timer = threading.Timer(seconds, fire)
+    timer.daemon = True
+    timer.start()
+    try:
+        return fn()
+    finally:
+        done.set()
+        timer.cancel()
+
+
 def main():
     args = parse()
     import torch
@@ -139,18 +230,7 @@ def main():
     pool = synthetic_images(min(B, 32), seed=1234 + rank)
     images = pool.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
     if train:
-        from image_captioning_amd import transformer_word_level_bahdnau as bah
-        from image_captioning_amd._bah_train import DropoutState
-        from image_captioning_amd.training import Trainer
-        model = bah.build_model(VOCAB, dropout=0.3)                       # transformer_word_level_bahdnau.py:171,183-188
-        model.load_state_dict(seeded_state_dict(model, seed=52))
-        model = model.to(dev)
-        DropoutState.manual_seed(1000 + rank)                             # dropout differs per rank, weights do not
-        trainer = Trainer(model, lr=1e-4, weight_decay=1e-5)              # :191
-        caps = synthetic_captions(B, CAPTION_LEN, VOCAB, 2, 3, 0, seed=77 + rank).to(dev)
-
-        def step():
-            return trainer.step(images, caps, 0)
+        model, step = build_train_step(torch, dev, rank, B)
     else:
         model = twl.build_model(VOCAB)
         model.load_state_dict(seeded_state_dict(model, seed=52))
@@ -235,6 +315,7 @@ def main():
                "unit": "captions/s", "ms_per_step": alt_elapsed / args.steps * 1e3,
                "tolerance": "features 1e-2, logits 2e-2 of their largest magnitude vs the f32 path (tests/test_gpu_bf16.py)"}
 
+    out = None
     if rank == 0:
         captions = world * B * args.steps
         dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom_events) / max(len(dom_events), 1)
@@ -251,10 +332,8 @@ def main():
         roof["traffic"] = pmc_traffic(roof["kernel"])
         roof["avg_launch_ms"] = dom_ms
         if train:
-            workload = ("transformer_word_level_bahdnau: teacher-forced training step (EfficientNet-B0 train mode + encoder block + "
-                        "Bahdanau LSTMCell decoder, compute_loss, backward, AdamW), fp32 (BASELINE configs[2] names bf16: not built yet)")
-            par = f"data-parallel x{world}, bucketed all-reduce of {sum(p.numel() for p in model.parameters()) * 4 / 1e6:.1f} MB of gradients" \
-                if world > 1 else "single GPU, no collective"
+            workload = TRAIN_WORKLOAD
+            par = train_parallelism(model, world)
         else:
             workload = ("transformer_word_level: EfficientNet-B0 encoder + word-level transformer decoder, "
                         "batched greedy captioning (BASELINE configs[1])")
@@ -272,6 +351,26 @@ def main():
             out["bf16_mode"] = alt
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_train_baseline(torch, model, min(B, 12)) if train else cpu_baseline(torch, model, args.cpu_sample)
+
+    # Secondary, after everything the contract asks for: the training half of the metric on the same ranks, so that the
+    # data-parallel path is measured wherever this line is.  It cannot take the line down with it: an exception becomes an
+    # "error" entry, and a rank that does not come back within the deadline prints the line without it and exits.
+    if not train and not args.no_train_mode:
+        def emit_without():
+            if rank == 0:
+                out["train"] = {"error": f"no result within {args.train_deadline:.0f} s"}
+                print(json.dumps(out), flush=True)
+
+        def run():
+            try:
+                return train_secondary(torch, dist, ops, dev, world, rank, max(1, min(args.steps, 10)))
+            except Exception as e:      # noqa: BLE001 - reported in the line
+                return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+        res = with_deadline(args.train_deadline, emit_without, run)
+        if rank == 0:
+            out["train"] = res
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

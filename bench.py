@@ -50,11 +50,15 @@ def parse():
                          "accumulation and fp32 tensors in memory (captioning mode only)")
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the secondary bf16-mode measurement")
     ap.add_argument("--no-train-mode", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--train-batch", type=int, default=256, help="images per step per GPU of the secondary training measurement")
     ap.add_argument("--train-deadline", type=float, default=240.0,
                     help="seconds the secondary training measurement may take before the line is printed without it")
     ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 1024 captioning, 256 training)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank dry run on fewer GPUs than ranks: gloo instead of RCCL, ranks share devices (numbers are not "
+                         "results; gloo's all-reduce of GPU tensors tends to stall in the training secondary, which the deadline cuts)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="images in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -150,6 +154,7 @@ def train_parallelism(model, world):
 
 
 def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
+    note(rank, f"train secondary: building the model, batch {B}")
     """The second half of the metric, measured after the contract's timed region on the same ranks: K training steps
     between barriers, max over ranks -> the "train" object of the JSON line."""
     model, step = build_train_step(torch, dev, rank, B)
@@ -159,10 +164,11 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.set_autotune(True)
+    ops.set_autotune(os.environ.get("ICAP_BENCH_NO_TUNE") != "1")
     step()
     torch.cuda.synchronize()
     ops.set_autotune(False)
+    note(rank, "train secondary: first step (tuning) done")
     for _ in range(2):
         step()
     barrier()
@@ -171,6 +177,7 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    note(rank, f"train secondary: {steps} steps in {elapsed:.2f} s")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,6 +209,14 @@ def with_deadline(seconds, on_timeout, fn):
         timer.cancel()
 
 
+T_START = time.perf_counter()
+
+
+def note(rank, msg):
+    """Progress on stderr (stdout carries only the JSON line); every rank reports, so a stuck rank can be told apart."""
+    print(f"[bench r{rank} +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -213,10 +228,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.rehearse:
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("ICAP_BENCH_DUMP_AFTER", "1e9")), repeat=True, file=sys.stderr)   # where a stuck rank is
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from image_captioning_amd import ops
     from image_captioning_amd import transformer_word_level as twl
@@ -267,11 +289,13 @@ def main():
             return ev
         return None
 
+    note(rank, f"process group and model ready ({'train' if train else 'caption'} mode, batch {B}, world {world})")
     ops.set_autotune(True)      # the first warm-up pass times the tile configurations of every GEMM shape once
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
     ops.set_autotune(False)
+    note(rank, "warm-up and tuning done")
     find_dominant()
     ops.set_trace(dom_trace)
 
@@ -287,6 +311,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_trace(None)
+    note(rank, f"timed region: {args.steps} steps in {elapsed:.2f} s")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -307,6 +332,7 @@ def main():
         barrier()
         alt_elapsed = time.perf_counter() - t1
         ops.set_compute_dtype("f32")
+        note(rank, f"bf16-mode secondary: {args.steps} steps in {alt_elapsed:.2f} s")
         if world > 1:
             t = torch.tensor([alt_elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -342,7 +368,7 @@ def main():
             "metric": "captions/sec greedy + train imgs/sec, 224px food imgs, 1/2/4/8 MI355X",
             "value": captions / elapsed, "unit": "imgs/s" if train else "captions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if (train or args.dtype == "f32") else "bf16 products / f32 accumulate / f32 storage except the fused expand+depthwise results (bf16)", "data": "synthetic",
+            "vs_baseline": None, **({"rehearsal": "gloo, shared devices: not a result"} if args.rehearse else {}), "dtype": "f32" if (train or args.dtype == "f32") else "bf16 products / f32 accumulate / f32 storage except the fused expand+depthwise results (bf16)", "data": "synthetic",
             "config": {"workload": workload, "images_per_step_per_gpu": B, "image": "3x224x224 fp32", "caption_tokens": CAPTION_LEN,
                        "vocab": VOCAB, "weights": "seeded random init", "parallelism": par},
             "roofline": roof,
@@ -363,7 +389,7 @@ def main():
 
         def run():
             try:
-                return train_secondary(torch, dist, ops, dev, world, rank, max(1, min(args.steps, 10)))
+                return train_secondary(torch, dist, ops, dev, world, rank, max(1, min(args.steps, 10)), args.train_batch)
             except Exception as e:      # noqa: BLE001 - reported in the line
                 return {"error": f"{type(e).__name__}: {e}"[:300]}
 

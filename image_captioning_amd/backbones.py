@@ -147,9 +147,9 @@ class ResNetTrunk(nn.Sequential):
             s = d["stride"]
             idn = x
             if d["down"] is not None:
-                idn = ops.conv2d(x, d["down"][0], *d["down"][1], stride=s)
-            h = ops.conv2d(x, d["w1"], *d["sb1"], stride=s, pad=(1, 1, 1, 1), act=ops.ACT_RELU)
-            x = ops.conv2d(h, d["w2"], *d["sb2"], residual=idn, pad=(1, 1, 1, 1), act=ops.ACT_RELU)
+                idn = ops.dense_conv(x, d["down"][0], d, "down16", *d["down"][1], stride=s)
+            h = ops.dense_conv(x, d["w1"], d, "w1_16", *d["sb1"], stride=s, pad=(1, 1, 1, 1), act=ops.ACT_RELU)
+            x = ops.dense_conv(h, d["w2"], d, "w2_16", *d["sb2"], residual=idn, pad=(1, 1, 1, 1), act=ops.ACT_RELU)
         x = ops.adaptive_avgpool2d(x, 1, 1)  # [B,1,1,512]
         return x.view(x.shape[0], 512, 1, 1)
 
@@ -199,7 +199,7 @@ class VGGTrunk(nn.Sequential):
         first = True
         for m in self:
             if isinstance(m, nn.Conv2d):
-                plan.append(("conv", conv_weight_khwc(m.weight, 4 if first else None), m.bias.float().contiguous()))
+                plan.append(("conv", conv_weight_khwc(m.weight, 4 if first else None), m.bias.float().contiguous(), {}))
                 first = False
             elif isinstance(m, nn.MaxPool2d):
                 plan.append(("pool",))
@@ -211,7 +211,7 @@ class VGGTrunk(nn.Sequential):
         x = ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)
         for st in plan:
             if st[0] == "conv":
-                x = ops.conv2d(x, st[1], None, st[2], pad=(1, 1, 1, 1), act=ops.ACT_RELU)
+                x = ops.dense_conv(x, st[1], st[3], "w16", None, st[2], pad=(1, 1, 1, 1), act=ops.ACT_RELU)
             else:
                 x = ops.maxpool2d(x, 2, 2, 0)
         if x.shape[1] != 7 or x.shape[2] != 7:

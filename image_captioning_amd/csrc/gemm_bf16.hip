@@ -8,6 +8,7 @@
 // registers -> LDS (double buffered, one barrier per step), LDS rows are padded to 80 bytes so that the 16-byte
 // fragment reads (lane (r, h) reads k = 8h .. 8h+7 of row r) are conflict free.  The epilogue transposes the
 // accumulators through LDS and writes 16 bytes per lane along the output row.
+#include <type_traits>
 #include "common.hpp"
 
 namespace icap {
@@ -28,6 +29,8 @@ struct GemmBf16Params {
     int M, N, K, hw, act, tiles_n;
     float* amax_val;        // optional [M][tiles_n]: per-tile row maxima of the outputs (arg-max partials)
     int* amax_idx;          // their column indices (first index on ties)
+    // CONV kernels only: x is an NHWC image [B][H][W][Cin], row m = (b, oh, ow), k = ((kh * KW) + kw) * Cin + c
+    int H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo;
 };
 
 constexpr int GB16_BK = 32;             // K elements per step (two MFMA K blocks)
@@ -40,8 +43,11 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 
 // A16: x is a bf16 tensor (the output of a fused kernel run with a bf16 result): its tile goes to LDS as loaded, or
 // through an fp32 multiply when the squeeze-excite gate applies.
-template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false>
+// CONV: implicit GEMM of a KH x KW convolution (Cin a multiple of 32, so that a 32-wide K slice lies inside one filter
+// tap): the A rows are gathered from the image on the fly, taps outside the image contribute zeros.
+template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) {
+    static_assert(!(CONV && (GATE || A16 || AMAX)), "the convolution form takes fp32 images and has no gate / arg-max");
     constexpr int BK = GB16_BK, LDK = GB16_LDK;
     constexpr int TM = BM / 2, TN = BN / 2, RM = TM / 32, RN = TN / 32;
     constexpr int AP = BM / 32;                    // staging passes over A: thread t -> row t/8 + 32 i, floats 4 (t%8) ..
@@ -70,13 +76,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
     const float* a_src[AP];
     const float* g_src[GATE ? AP : 1];
     bool a_ok[AP];
+    int a_ih[CONV ? AP : 1], a_iw[CONV ? AP : 1];      // CONV: input coordinates of filter tap (0, 0) for this row
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + a_row + 32 * i;
         a_ok[i] = m < p.M;
-        a_src[i] = p.x + (size_t)(a_ok[i] ? m : 0) * p.K;
+        if constexpr (CONV) {
+            const int mm = a_ok[i] ? m : 0;
+            const int b = mm / (p.Ho * p.Wo), r = mm - b * (p.Ho * p.Wo);
+            const int oh = r / p.Wo, ow = r - oh * p.Wo;
+            a_ih[i] = oh * p.stride - p.pad_t;
+            a_iw[i] = ow * p.stride - p.pad_l;
+            a_src[i] = p.x + (size_t)b * p.H * p.W * p.Cin;
+        } else {
+            a_src[i] = p.x + (size_t)(a_ok[i] ? m : 0) * p.K;
+        }
         if (GATE) g_src[i] = p.gate + (size_t)((a_ok[i] ? m : 0) / p.hw) * p.K;
     }
+    int c_kh = 0, c_kw = 0, c_c0 = 0;                   // CONV: filter tap and first channel of the slice gload fetches next
     // bf16 A: staged like W (thread t -> row t/4 + 64 i, eight bf16 at 8 (t%4))
     constexpr int AP16 = (BM + 63) / 64;
     const unsigned short* a16_src[A16 ? AP16 : 1];
@@ -123,10 +140,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
         }
 #pragma unroll
         for (int i = 0; i < (A16 ? 0 : AP); ++i) {
-            const bool ok = a_ok[i] && ka < p.K;
-            ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ka : p.x);
-            if (GATE) rg[i] = *reinterpret_cast<const float4*>(ok ? g_src[i] + ka : p.gate);
-            okmask |= ok ? (1u << i) : 0u;
+            if constexpr (CONV) {
+                const int ih = a_ih[i] + c_kh, iw = a_iw[i] + c_kw;
+                const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ((size_t)ih * p.W + iw) * p.Cin + c_c0 + a_k4 : p.x);
+                okmask |= ok ? (1u << i) : 0u;
+            } else {
+                const bool ok = a_ok[i] && ka < p.K;
+                ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ka : p.x);
+                if (GATE) rg[i] = *reinterpret_cast<const float4*>(ok ? g_src[i] + ka : p.gate);
+                okmask |= ok ? (1u << i) : 0u;
+            }
+        }
+        if constexpr (CONV) {       // slices are fetched in order: step the tap
+            c_c0 += BK;
+            if (c_c0 == p.Cin) {
+                c_c0 = 0;
+                if (++c_kw == p.KW) { c_kw = 0; ++c_kh; }
+            }
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
@@ -328,6 +359,55 @@ int linear_bf16_f32(const void* xv, int x_bf16, const unsigned short* w, const f
         default: set_error("linear_bf16: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
     }
     return launch_status("linear_bf16");
+}
+
+// KH x KW convolution, NHWC fp32 image, bf16 weights [Cout][KH][KW][Cin] (Cin % 32 == 0), fused scale / bias / residual /
+// activation: the dense 3x3 layers of the ResNet-18 and VGG-16 encoders in bf16 compute mode.
+// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles.
+int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale, const float* bias, const float* residual, float* y,
+                    int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                    int cfg, hipStream_t st) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_t < 0 ||
+        pad_l < 0 || Ho <= 0 || Wo <= 0) {
+        set_error("conv2d_bf16: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if ((Ho - 1) * stride - pad_t >= H || (Wo - 1) * stride - pad_l >= W) {      // the last window must still touch the image
+        set_error("conv2d_bf16: output size %dx%d does not fit input %dx%d", Ho, Wo, H, W);
+        return ICAP_ERR_ARG;
+    }
+    if (Cin % 32 || Cout % 4) { set_error("conv2d_bf16: Cin=%d must be a multiple of 32 and Cout=%d of 4", Cin, Cout); return ICAP_ERR_ALIGN; }
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (scale && !aligned16(scale)) || (bias && !aligned16(bias)) ||
+        (residual && !aligned16(residual))) {
+        set_error("conv2d_bf16: pointers must be 16-byte aligned");
+        return ICAP_ERR_ALIGN;
+    }
+    const long long M = (long long)B * Ho * Wo, K = (long long)KH * KW * Cin;
+    if (M > 0x7fffffffLL || K > 0x7fffffffLL || M * Cout > (1LL << 40) || ((M + 63) / 64) * ((Cout + 63) / 64) > 0x7fffffffLL) {
+        set_error("conv2d_bf16: problem too large");
+        return ICAP_ERR_LIMIT;
+    }
+    GemmBf16Params p{x, w, scale, bias, residual, nullptr, y, (int)M, Cout, (int)K, 1, act, 0, nullptr, nullptr,
+                     H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo};
+    if (cfg < 0) {
+        const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+        if (Cout > 64 && t128 >= 512) cfg = 0;
+        else if (((M + 127) / 128) * ((Cout + 63) / 64) >= 512) cfg = 1;
+        else cfg = 2;
+    }
+    auto launch = [&](auto bm, auto bn) {
+        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
+        p.tiles_n = (p.N + BN - 1) / BN;
+        const dim3 grid((unsigned)((long long)((p.M + BM - 1) / BM) * p.tiles_n)), block(256);
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, false, true>), grid, block, 0, st, p);
+    };
+    switch (cfg) {
+        case 0: launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{}); break;
+        case 1: launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 64>{}); break;
+        case 2: launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{}); break;
+        default: set_error("conv2d_bf16: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
+    }
+    return launch_status("conv2d_bf16");
 }
 
 // Linear layer whose epilogue also emits, per output row and 128-column tile, the maximum and its column (first index on

@@ -59,6 +59,30 @@ def pointwise_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=N
     return conv2d(x, w, scale, bias, residual=residual, gate=gate, act=act)
 
 
+def dense_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None, *, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE):
+    """KH x KW convolution (conv2d's arguments): the fp32 implicit-GEMM kernel, or - in bf16 compute mode and for
+    Cin % 32 == 0, Cout % 4 == 0 - icap_conv2d_bf16_f32 with a cached bf16 copy of the weight."""
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    if not (COMPUTE_DTYPE == "bf16" and Cin % 32 == 0 and Cout % 4 == 0):
+        return conv2d(x, w, scale, bias, residual=residual, stride=stride, pad=pad, act=act)
+    w16 = w16_cache.get(key)
+    if w16 is None:
+        w16 = w16_cache[key] = to_bf16(w.contiguous())
+    pt, pb, pl, pr = pad
+    Ho = conv_out_size(H, KH, stride, pt, pb)
+    Wo = conv_out_size(W, KW, stride, pl, pr)
+    out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    if residual is not None and residual.numel() != out.numel():
+        raise IcapError("dense_conv: residual has the wrong size")
+    span = _Span("conv2d_bf16", (B, H, W, Cin, Cout, KH, stride, Ho, Wo, residual is not None))
+    N.check(N.load().icap_conv2d_bf16_f32(_ck(x, "x"), _ck(w16, "w", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
+                                          _ck(residual, "residual"), _ck(out, "out"), B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo,
+                                          act, -1, _stream()), "conv2d_bf16")
+    span.done()
+    return out
+
+
 def bf16_activations_ok(cin: int, cout: int) -> bool:
     """True when a [.., cin] activation may be handed to pointwise_conv as bf16 (bf16 mode and a shape its kernel takes)."""
     return COMPUTE_DTYPE == "bf16" and cin % 8 == 0 and cout % 4 == 0

@@ -162,6 +162,15 @@ int icap_linear_bf16_f32(const void* x, int x_bf16, const unsigned short* w_bf16
                          void* stream);
 int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* stream);
 
+/* bf16-product form of icap_conv2d_f32 for the dense KH x KW convolutions of the ResNet-18 / VGG-16 encoders
+ * (seq2seqbasic.py:19-35: torchvision conv3x3 + BN + ReLU, residual add): x [B][H][W][Cin] fp32 NHWC with Cin % 32 == 0,
+ * w_bf16 [Cout][KH][KW][Cin] from icap_to_bf16_f32, fp32 accumulation, y = act(conv * scale + bias (+ residual)) fp32
+ * [B][Ho][Wo][Cout]; taps outside the image are zeros (pad_t / pad_l; bottom / right padding follows from Ho / Wo).
+ * cfg: -1 = by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles. */
+int icap_conv2d_bf16_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias, const float* residual,
+                         float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
+                         int Wo, int act, int cfg, void* stream);
+
 /* icap_linear_bf16_f32 (no residual / gate / activation) whose epilogue also writes arg-max partials: per row and
  * 128-column tile the maximum and its column, part_val / part_idx [M][icap_linear_bf16_argmax_parts(N)], consumed by
  * icap_next_token_f32; y may be NULL.  The bf16-mode form of icap_linear_argmax_f32 (greedy TransformerTest.py:147-157). */

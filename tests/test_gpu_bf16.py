@@ -154,3 +154,56 @@ def test_linear_bf16_argmax_partials(bf16_mode, M, K, N):
     assert torch.equal(pv.max(1).values, ref.max(1).values)
     pv2, pi2, none = ops.linear_bf16_argmax(x.to(D), w16, b.to(D))
     assert none is None and torch.equal(pv2, pv) and torch.equal(pi2, pi)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,stride,pad,res", [(2, 14, 14, 64, 64, 3, 1, (1, 1, 1, 1), True), (3, 9, 11, 32, 132, 3, 2, (1, 1, 1, 1), False),
+                                                             (2, 28, 28, 128, 256, 1, 2, (0, 0, 0, 0), False), (1, 7, 7, 512, 512, 3, 1, (1, 1, 1, 1), True),
+                                                             (5, 20, 16, 96, 40, 5, 1, (2, 2, 2, 2), False)])
+def test_dense_conv_bf16(bf16_mode, B, H, W, Cin, Cout, K, stride, pad, res):
+    """The bf16 implicit-GEMM convolution against torch on bf16-rounded operands (exact products, fp32 accumulation)."""
+    import torch.nn.functional as F
+    ops = bf16_mode
+    g = torch.Generator().manual_seed(B * 100 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) * (Cin * K * K) ** -0.5
+    sc, bi = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    xb, wb = x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double()
+    ref = F.conv2d(F.pad(xb, (pad[2], pad[3], pad[0], pad[1])), wb, stride=stride) * sc.double()[None, :, None, None] + bi.double()[None, :, None, None]
+    r = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + r.double()
+    ref = torch.relu(ref).float()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(D)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(D)
+    rd = r.permute(0, 2, 3, 1).contiguous().to(D) if res else None
+    cache = {}
+    ops.set_compute_dtype("bf16")
+    y = ops.dense_conv(xd, wd, cache, "k", sc.to(D), bi.to(D), residual=rd, stride=stride, pad=pad, act=ops.ACT_RELU)
+    assert cache["k"].dtype == torch.bfloat16
+    torch.testing.assert_close(y.permute(0, 3, 1, 2).cpu(), ref, rtol=1e-4, atol=1e-4)
+    ops.set_compute_dtype("f32")
+    y32 = ops.dense_conv(xd, wd, {}, "k", sc.to(D), bi.to(D), residual=rd, stride=stride, pad=pad, act=ops.ACT_RELU)
+    assert float((y - y32).abs().max()) <= 2e-2 * float(y32.abs().max())           # stated bf16 tolerance vs the fp32 kernel
+    ops.set_compute_dtype("bf16")
+    x12 = torch.randn(1, 5, 5, 12, device=D)                                         # Cin % 32 != 0 stays on the fp32 kernel
+    w12 = torch.randn(8, 3, 3, 12, device=D)
+    c2 = {}
+    ops.dense_conv(x12, w12, c2, "k", pad=(1, 1, 1, 1))
+    assert not c2
+
+
+@pytest.mark.parametrize("kind", ["resnet18", "vgg16"])
+def test_dense_encoders_bf16_mode_track_fp32(bf16_mode, kind):
+    ops = bf16_mode
+    from image_captioning_amd import seq2seqbasic as s2s
+    from image_captioning_amd.synthetic import seeded_state_dict
+    enc = s2s.EncoderCNN(256, cnn_type=kind)
+    enc.load_state_dict(seeded_state_dict(enc, seed=9))
+    enc = enc.to(D).eval()
+    imgs = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(4)).to(D)
+    ops.set_compute_dtype("f32")
+    f32 = enc(imgs).clone()
+    ops.set_compute_dtype("bf16")
+    f16 = enc(imgs).clone()
+    assert not torch.equal(f32, f16)
+    assert float((f32 - f16).abs().max()) <= 1e-2 * float(f32.abs().max())

@@ -109,7 +109,7 @@ def stem_dw_work(sig):
     return 2.0 * B * Hs * Ws * 27 * C + 2.0 * B * Ho * Wo * C * 9, 4.0 * B * H * W * 4 + ob * B * Ho * Wo * C
 
 
-WORK = {"linear_bf16": lambda s: linear_bf16_work(s), "stem_dwconv2d": stem_dw_work, "conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work, "expand_dwconv2d": expand_dw_work,
+WORK = {"linear_bf16": lambda s: linear_bf16_work(s), "conv2d_bf16": lambda s: conv_work(tuple(s[:10]) + (False,)), "stem_dwconv2d": stem_dw_work, "conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work, "expand_dwconv2d": expand_dw_work,
         # training-step launches: (flops, algorithmic bytes)
         "gemm_nn": gemm_work, "gemm_tn": gemm_work,
         "col_reduce": lambda s: (2.0 * s[1] * s[2], 4.0 * s[1] * s[2] * (2 if s[0] >= 2 else 1)),

@@ -141,7 +141,7 @@ class ResNetTrunk(nn.Sequential):
         require_eval(self, "ResNet-18 trunk")
         p = self._prep.get(self, self._build)
         x = ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)
-        x = ops.conv2d(x, p["stem_w"], *p["stem_sb"], stride=2, pad=(3, 3, 3, 3), act=ops.ACT_RELU)
+        x = ops.dense_conv(x, p["stem_w"], p, "stem16", *p["stem_sb"], stride=2, pad=(3, 3, 3, 3), act=ops.ACT_RELU)
         x = ops.maxpool2d(x, 3, 2, 1)
         for d in p["blocks"]:
             s = d["stride"]

@@ -30,7 +30,7 @@ struct GemmBf16Params {
     float* amax_val;        // optional [M][tiles_n]: per-tile row maxima of the outputs (arg-max partials)
     int* amax_idx;          // their column indices (first index on ties)
     // CONV kernels only: x is an NHWC image [B][H][W][Cin], row m = (b, oh, ow), k = ((kh * KW) + kw) * Cin + c
-    int H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo;
+    int H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo, KHW;
 };
 
 constexpr int GB16_BK = 32;             // K elements per step (two MFMA K blocks)
@@ -43,9 +43,11 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 
 // A16: x is a bf16 tensor (the output of a fused kernel run with a bf16 result): its tile goes to LDS as loaded, or
 // through an fp32 multiply when the squeeze-excite gate applies.
-// CONV: implicit GEMM of a KH x KW convolution (Cin a multiple of 32, so that a 32-wide K slice lies inside one filter
-// tap): the A rows are gathered from the image on the fly, taps outside the image contribute zeros.
-template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, bool CONV = false>
+// CONV: implicit GEMM of a KH x KW convolution: the A rows are gathered from the image on the fly, taps outside the image
+// contribute zeros.  CONV = 1: Cin a multiple of 32, so a 32-wide K slice lies inside one filter tap.  CONV = 2: Cin = 4
+// (the channel-padded RGB image): a slice covers 8 taps, one per staging lane; the weight rows are zero-padded to a
+// multiple of 32 and taps beyond KH * KW read as zeros.
+template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, int CONV = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) {
     static_assert(!(CONV && (GATE || A16 || AMAX)), "the convolution form takes fp32 images and has no gate / arg-max");
     constexpr int BK = GB16_BK, LDK = GB16_LDK;
@@ -140,10 +142,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
         }
 #pragma unroll
         for (int i = 0; i < (A16 ? 0 : AP); ++i) {
-            if constexpr (CONV) {
+            if constexpr (CONV == 1) {
                 const int ih = a_ih[i] + c_kh, iw = a_iw[i] + c_kw;
                 const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ((size_t)ih * p.W + iw) * p.Cin + c_c0 + a_k4 : p.x);
+                okmask |= ok ? (1u << i) : 0u;
+            } else if constexpr (CONV == 2) {
+                const int tap = (ka >> 2), kh = tap / p.KW, kw = tap - kh * p.KW;
+                const int ih = a_ih[i] + kh, iw = a_iw[i] + kw;
+                const bool ok = a_ok[i] && tap < p.KHW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ((size_t)ih * p.W + iw) * 4 : p.x);
                 okmask |= ok ? (1u << i) : 0u;
             } else {
                 const bool ok = a_ok[i] && ka < p.K;
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
                 okmask |= ok ? (1u << i) : 0u;
             }
         }
-        if constexpr (CONV) {       // slices are fetched in order: step the tap
+        if constexpr (CONV == 1) {  // slices are fetched in order: step the tap
             c_c0 += BK;
             if (c_c0 == p.Cin) {
                 c_c0 = 0;
@@ -361,8 +369,9 @@ int linear_bf16_f32(const void* xv, int x_bf16, const unsigned short* w, const f
     return launch_status("linear_bf16");
 }
 
-// KH x KW convolution, NHWC fp32 image, bf16 weights [Cout][KH][KW][Cin] (Cin % 32 == 0), fused scale / bias / residual /
-// activation: the dense 3x3 layers of the ResNet-18 and VGG-16 encoders in bf16 compute mode.
+// KH x KW convolution, NHWC fp32 image, bf16 weights [Cout][KH][KW][Cin] (Cin % 32 == 0; or Cin == 4 with every weight
+// row zero-padded from KH*KW*4 to a multiple of 32 values), fused scale / bias / residual / activation: the dense layers
+// of the ResNet-18 and VGG-16 encoders in bf16 compute mode.
 // cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles.
 int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale, const float* bias, const float* residual, float* y,
                     int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
@@ -376,19 +385,23 @@ int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale,
         set_error("conv2d_bf16: output size %dx%d does not fit input %dx%d", Ho, Wo, H, W);
         return ICAP_ERR_ARG;
     }
-    if (Cin % 32 || Cout % 4) { set_error("conv2d_bf16: Cin=%d must be a multiple of 32 and Cout=%d of 4", Cin, Cout); return ICAP_ERR_ALIGN; }
+    if ((Cin % 32 && Cin != 4) || Cout % 4) {
+        set_error("conv2d_bf16: Cin=%d must be 4 or a multiple of 32, and Cout=%d a multiple of 4", Cin, Cout);
+        return ICAP_ERR_ALIGN;
+    }
     if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (scale && !aligned16(scale)) || (bias && !aligned16(bias)) ||
         (residual && !aligned16(residual))) {
         set_error("conv2d_bf16: pointers must be 16-byte aligned");
         return ICAP_ERR_ALIGN;
     }
-    const long long M = (long long)B * Ho * Wo, K = (long long)KH * KW * Cin;
+    // Cin = 4: the weight rows hold KH * KW * 4 values padded with zeros to a multiple of 32
+    const long long M = (long long)B * Ho * Wo, K = Cin == 4 ? ((long long)KH * KW * 4 + 31) / 32 * 32 : (long long)KH * KW * Cin;
     if (M > 0x7fffffffLL || K > 0x7fffffffLL || M * Cout > (1LL << 40) || ((M + 63) / 64) * ((Cout + 63) / 64) > 0x7fffffffLL) {
         set_error("conv2d_bf16: problem too large");
         return ICAP_ERR_LIMIT;
     }
     GemmBf16Params p{x, w, scale, bias, residual, nullptr, y, (int)M, Cout, (int)K, 1, act, 0, nullptr, nullptr,
-                     H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo};
+                     H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo, KH * KW};
     if (cfg < 0) {
         const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
         if (Cout > 64 && t128 >= 512) cfg = 0;
@@ -399,7 +412,8 @@ int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale,
         constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
         p.tiles_n = (p.N + BN - 1) / BN;
         const dim3 grid((unsigned)((long long)((p.M + BM - 1) / BM) * p.tiles_n)), block(256);
-        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, false, true>), grid, block, 0, st, p);
+        if (Cin == 4) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, false, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, false, 1>), grid, block, 0, st, p);
     };
     switch (cfg) {
         case 0: launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{}); break;

@@ -61,14 +61,18 @@ def pointwise_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=N
 
 def dense_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None, *, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE):
     """KH x KW convolution (conv2d's arguments): the fp32 implicit-GEMM kernel, or - in bf16 compute mode and for
-    Cin % 32 == 0, Cout % 4 == 0 - icap_conv2d_bf16_f32 with a cached bf16 copy of the weight."""
+    Cin % 32 == 0 (or the 4-channel padded image), Cout % 4 == 0 - icap_conv2d_bf16_f32 with a cached bf16 copy of the weight."""
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
-    if not (COMPUTE_DTYPE == "bf16" and Cin % 32 == 0 and Cout % 4 == 0):
+    if not (COMPUTE_DTYPE == "bf16" and (Cin % 32 == 0 or Cin == 4) and Cout % 4 == 0):
         return conv2d(x, w, scale, bias, residual=residual, stride=stride, pad=pad, act=act)
     w16 = w16_cache.get(key)
     if w16 is None:
-        w16 = w16_cache[key] = to_bf16(w.contiguous())
+        wk = w.contiguous()
+        if Cin == 4:    # K = KH*KW*4 padded with zeros to a multiple of 32 (the kernel reads taps beyond KH*KW as zeros)
+            k = KH * KW * 4
+            wk = torch.nn.functional.pad(wk.view(Cout, k), (0, (k + 31) // 32 * 32 - k)).contiguous()
+        w16 = w16_cache[key] = to_bf16(wk)
     pt, pb, pl, pr = pad
     Ho = conv_out_size(H, KH, stride, pt, pb)
     Wo = conv_out_size(W, KW, stride, pl, pr)

@@ -164,7 +164,8 @@ int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* s
 
 /* bf16-product form of icap_conv2d_f32 for the dense KH x KW convolutions of the ResNet-18 / VGG-16 encoders
  * (seq2seqbasic.py:19-35: torchvision conv3x3 + BN + ReLU, residual add): x [B][H][W][Cin] fp32 NHWC with Cin % 32 == 0,
- * w_bf16 [Cout][KH][KW][Cin] from icap_to_bf16_f32, fp32 accumulation, y = act(conv * scale + bias (+ residual)) fp32
+ * w_bf16 [Cout][KH][KW][Cin] from icap_to_bf16_f32 - or Cin == 4 (the channel-padded RGB image of the first layer) with
+ * every weight row zero-padded from KH*KW*4 to the next multiple of 32 values - fp32 accumulation, y = act(conv * scale + bias (+ residual)) fp32
  * [B][Ho][Wo][Cout]; taps outside the image are zeros (pad_t / pad_l; bottom / right padding follows from Ho / Wo).
  * cfg: -1 = by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles. */
 int icap_conv2d_bf16_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias, const float* residual,

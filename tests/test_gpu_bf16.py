@@ -158,7 +158,8 @@ def test_linear_bf16_argmax_partials(bf16_mode, M, K, N):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,K,stride,pad,res", [(2, 14, 14, 64, 64, 3, 1, (1, 1, 1, 1), True), (3, 9, 11, 32, 132, 3, 2, (1, 1, 1, 1), False),
                                                              (2, 28, 28, 128, 256, 1, 2, (0, 0, 0, 0), False), (1, 7, 7, 512, 512, 3, 1, (1, 1, 1, 1), True),
-                                                             (5, 20, 16, 96, 40, 5, 1, (2, 2, 2, 2), False)])
+                                                             (5, 20, 16, 96, 40, 5, 1, (2, 2, 2, 2), False),
+                                                             (2, 37, 41, 4, 64, 7, 2, (3, 3, 3, 3), False), (2, 18, 18, 4, 36, 3, 1, (1, 1, 1, 1), False)])
 def test_dense_conv_bf16(bf16_mode, B, H, W, Cin, Cout, K, stride, pad, res):
     """The bf16 implicit-GEMM convolution against torch on bf16-rounded operands (exact products, fp32 accumulation)."""
     import torch.nn.functional as F

@@ -338,7 +338,7 @@ static void gb16_launch(GemmBf16Params& p, bool a16, hipStream_t st) {
     }
 }
 
-// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles; x_bf16: x points to a bf16 [M][K] tensor.
+// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256 tiles; x_bf16: x points to a bf16 [M][K] tensor.
 int linear_bf16_f32(const void* xv, int x_bf16, const unsigned short* w, const float* scale, const float* bias, const float* residual,
                     const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, hipStream_t st) {
     const float* x = reinterpret_cast<const float*>(xv);
@@ -355,15 +355,18 @@ int linear_bf16_f32(const void* xv, int x_bf16, const unsigned short* w, const f
     }
     GemmBf16Params p{x, w, scale, bias, residual, gate, y, M, N, K, gate ? hw : 1, act, 0, nullptr, nullptr};
     if (cfg < 0) {
-        const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-        if (N > 64 && t128 >= 512) cfg = 0;
-        else if ((long long)((M + 127) / 128) * ((N + 63) / 64) >= 512) cfg = 1;
+        // the A tile is re-used across the tile's columns, so wide tiles cut the (fp32) activation traffic per flop
+        const long long mt = (M + 127) / 128;
+        if (N >= 256 && mt * ((N + 255) / 256) >= 256) cfg = 3;
+        else if (N > 64 && mt * ((N + 127) / 128) >= 512) cfg = 0;
+        else if (mt * ((N + 63) / 64) >= 512) cfg = 1;
         else cfg = 2;
     }
     switch (cfg) {
         case 0: gb16_launch<128, 128>(p, x_bf16 != 0, st); break;
         case 1: gb16_launch<128, 64>(p, x_bf16 != 0, st); break;
         case 2: gb16_launch<64, 64>(p, x_bf16 != 0, st); break;
+        case 3: gb16_launch<128, 256>(p, x_bf16 != 0, st); break;
         default: set_error("linear_bf16: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
     }
     return launch_status("linear_bf16");
@@ -372,7 +375,7 @@ int linear_bf16_f32(const void* xv, int x_bf16, const unsigned short* w, const f
 // KH x KW convolution, NHWC fp32 image, bf16 weights [Cout][KH][KW][Cin] (Cin % 32 == 0; or Cin == 4 with every weight
 // row zero-padded from KH*KW*4 to a multiple of 32 values), fused scale / bias / residual / activation: the dense layers
 // of the ResNet-18 and VGG-16 encoders in bf16 compute mode.
-// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles.
+// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256, 4 = 256x128 tiles.
 int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale, const float* bias, const float* residual, float* y,
                     int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
                     int cfg, hipStream_t st) {
@@ -403,9 +406,10 @@ int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale,
     GemmBf16Params p{x, w, scale, bias, residual, nullptr, y, (int)M, Cout, (int)K, 1, act, 0, nullptr, nullptr,
                      H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo, KH * KW};
     if (cfg < 0) {
-        const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
-        if (Cout > 64 && t128 >= 512) cfg = 0;
-        else if (((M + 127) / 128) * ((Cout + 63) / 64) >= 512) cfg = 1;
+        const long long mt = (M + 127) / 128;
+        if (Cout >= 256 && mt * ((Cout + 255) / 256) >= 256) cfg = 3;
+        else if (Cout > 64 && mt * ((Cout + 127) / 128) >= 256) cfg = 0;
+        else if (mt * ((Cout + 63) / 64) >= 512) cfg = 1;
         else cfg = 2;
     }
     auto launch = [&](auto bm, auto bn) {
@@ -419,6 +423,8 @@ int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale,
         case 0: launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{}); break;
         case 1: launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 64>{}); break;
         case 2: launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{}); break;
+        case 3: launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 256>{}); break;
+        case 4: launch(std::integral_constant<int, 256>{}, std::integral_constant<int, 128>{}); break;
         default: set_error("conv2d_bf16: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
     }
     return launch_status("conv2d_bf16");

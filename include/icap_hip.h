@@ -154,7 +154,7 @@ int icap_argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_st
  * v_mfma_f32_32x32x16_bf16):  y[M][N] = act((x[M][K] (* gate[m / hw][k]) @ w^T) * scale[n] + bias[n] (+ residual[m][n])),
  * w_bf16 [N][K] as produced by icap_to_bf16_f32 (round to nearest even); x is fp32, or bf16 when x_bf16 = 1 (the bf16
  * result of a fused kernel).  K % 8 == 0, N % 4 == 0.  cfg -1 picks the
- * tile shape (0: 128x128, 1: 128x64, 2: 64x64).  Same layers as icap_conv2d_f32 with KH = KW = 1 - MBConv `_expand_conv`,
+ * tile shape (0: 128x128, 1: 128x64, 2: 64x64, 3: 128x256).  Same layers as icap_conv2d_f32 with KH = KW = 1 - MBConv `_expand_conv`,
  * `_project_conv`, `_conv_head` (transformer_word_level.py:13) and every nn.Linear of the decoders - at the precision
  * north-star configuration names for the accelerated path. */
 int icap_linear_bf16_f32(const void* x, int x_bf16, const unsigned short* w_bf16, const float* scale, const float* bias,
@@ -167,7 +167,7 @@ int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* s
  * w_bf16 [Cout][KH][KW][Cin] from icap_to_bf16_f32 - or Cin == 4 (the channel-padded RGB image of the first layer) with
  * every weight row zero-padded from KH*KW*4 to the next multiple of 32 values - fp32 accumulation, y = act(conv * scale + bias (+ residual)) fp32
  * [B][Ho][Wo][Cout]; taps outside the image are zeros (pad_t / pad_l; bottom / right padding follows from Ho / Wo).
- * cfg: -1 = by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64 tiles. */
+ * cfg: -1 = by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256, 4 = 256x128 tiles. */
 int icap_conv2d_bf16_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias, const float* residual,
                          float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
                          int Wo, int act, int cfg, void* stream);

@@ -123,7 +123,9 @@ SIGNATURES = {
     "icap_dwconv_bwd_weight_f32": (_i, [_p, _p] + [_i] * 10 + [_p, _p, _p]),
     "icap_dwconv_bwd_weight_ws_floats": (_ll, [_i] * 5),
     "icap_transpose_f32": (_i, [_p, _i, _i, _i, _p, _p]),
-    "icap_conv2d_bf16_f32": (_i, [_p] * 6 + [_i] * 14 + [_p]),
+    "icap_conv2d_bf16_f32": (_i, [_p] * 6 + [_i] * 15 + [_p]),
+    "icap_maxpool2d_bf16": (_i, [_p, _p] + [_i] * 9 + [_p]),
+    "icap_adaptive_avgpool2d_bf16_f32": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "icap_resize_normalize_ws_bytes": (C.c_longlong, [_i, _i, _i]),
     "icap_resize_normalize_u8_f32": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "icap_im2col_f32": (_i, [_p] + [_i] * 11 + [_p, _p]),

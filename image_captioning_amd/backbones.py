@@ -141,15 +141,20 @@ class ResNetTrunk(nn.Sequential):
         require_eval(self, "ResNet-18 trunk")
         p = self._prep.get(self, self._build)
         x = ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)
-        x = ops.dense_conv(x, p["stem_w"], p, "stem16", *p["stem_sb"], stride=2, pad=(3, 3, 3, 3), act=ops.ACT_RELU)
+        # in bf16 compute mode the activations stay in bf16 from the stem to the global average pool
+        k16 = ops.bf16_storage_ok
+        x = ops.dense_conv(x, p["stem_w"], p, "stem16", *p["stem_sb"], stride=2, pad=(3, 3, 3, 3), act=ops.ACT_RELU,
+                           out_bf16=k16(4, p["stem_w"].shape[0]))
         x = ops.maxpool2d(x, 3, 2, 1)
         for d in p["blocks"]:
             s = d["stride"]
             idn = x
+            cin, cout = x.shape[3], d["w1"].shape[0]
+            o16 = x.dtype == torch.bfloat16 and k16(cin, cout)
             if d["down"] is not None:
-                idn = ops.dense_conv(x, d["down"][0], d, "down16", *d["down"][1], stride=s)
-            h = ops.dense_conv(x, d["w1"], d, "w1_16", *d["sb1"], stride=s, pad=(1, 1, 1, 1), act=ops.ACT_RELU)
-            x = ops.dense_conv(h, d["w2"], d, "w2_16", *d["sb2"], residual=idn, pad=(1, 1, 1, 1), act=ops.ACT_RELU)
+                idn = ops.dense_conv(x, d["down"][0], d, "down16", *d["down"][1], stride=s, out_bf16=o16)
+            h = ops.dense_conv(x, d["w1"], d, "w1_16", *d["sb1"], stride=s, pad=(1, 1, 1, 1), act=ops.ACT_RELU, out_bf16=o16)
+            x = ops.dense_conv(h, d["w2"], d, "w2_16", *d["sb2"], residual=idn, pad=(1, 1, 1, 1), act=ops.ACT_RELU, out_bf16=o16)
         x = ops.adaptive_avgpool2d(x, 1, 1)  # [B,1,1,512]
         return x.view(x.shape[0], 512, 1, 1)
 
@@ -211,11 +216,13 @@ class VGGTrunk(nn.Sequential):
         x = ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)
         for st in plan:
             if st[0] == "conv":
-                x = ops.dense_conv(x, st[1], st[3], "w16", None, st[2], pad=(1, 1, 1, 1), act=ops.ACT_RELU)
+                # in bf16 compute mode the activations stay in bf16 up to the 7x7 pooling
+                x = ops.dense_conv(x, st[1], st[3], "w16", None, st[2], pad=(1, 1, 1, 1), act=ops.ACT_RELU,
+                                   out_bf16=ops.bf16_storage_ok(x.shape[3], st[1].shape[0]))
             else:
                 x = ops.maxpool2d(x, 2, 2, 0)
-        if x.shape[1] != 7 or x.shape[2] != 7:
-            x = ops.adaptive_avgpool2d(x, 7, 7)
+        if x.shape[1] != 7 or x.shape[2] != 7 or x.dtype != torch.float32:
+            x = ops.adaptive_avgpool2d(x, 7, 7)      # (also the bf16 -> fp32 step when the map is 7x7 already)
         return x.reshape(x.shape[0], -1)
 
 

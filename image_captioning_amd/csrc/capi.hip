@@ -30,8 +30,10 @@ int next_token_f32(const float*, const int*, int, long long*, int, const float*,
 int linear_bf16_f32(const void*, int, const unsigned short*, const float*, const float*, const float*, const float*, int, float*, int,
                     int, int, int, int, hipStream_t);
 int to_bf16_f32(const float*, unsigned short*, long long, hipStream_t);
-int conv2d_bf16_f32(const float*, const unsigned short*, const float*, const float*, const float*, float*, int, int, int, int, int, int,
-                    int, int, int, int, int, int, int, int, hipStream_t);
+int conv2d_bf16_f32(const void*, const unsigned short*, const float*, const float*, const void*, void*, int, int, int, int, int, int,
+                    int, int, int, int, int, int, int, int, int, hipStream_t);
+int maxpool2d_bf16(const unsigned short*, unsigned short*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int adaptive_avgpool2d_bf16_f32(const unsigned short*, float*, int, int, int, int, int, int, hipStream_t);
 int linear_bf16_argmax_parts(int);
 int linear_bf16_argmax_f32(const float*, const unsigned short*, const float*, const float*, float*, float*, int*, int, int, int, hipStream_t);
 int topk_sample_f32(const float*, int, int, int, int, unsigned long long, unsigned long long, float*, int*, long long*, int, hipStream_t);
@@ -580,11 +582,20 @@ int icap_dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, in
 }
 long long icap_dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K) { return dwconv_bwd_weight_ws_floats(B, Ho, Wo, C, K); }
 
-int icap_conv2d_bf16_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias, const float* residual,
-                         float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
-                         int Wo, int act, int cfg, void* stream) {
-    return conv2d_bf16_f32(x, w_bf16, scale, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, cfg,
-                           (hipStream_t)stream);
+int icap_conv2d_bf16_f32(const void* x, const unsigned short* w_bf16, const float* scale, const float* bias, const void* residual,
+                         void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
+                         int Wo, int act, int io_bf16, int cfg, void* stream) {
+    return conv2d_bf16_f32(x, w_bf16, scale, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, io_bf16,
+                           cfg, (hipStream_t)stream);
+}
+
+int icap_maxpool2d_bf16(const unsigned short* x, unsigned short* y, int B, int H, int W, int C, int ks, int stride, int pad, int Ho,
+                        int Wo, void* stream) {
+    return maxpool2d_bf16(x, y, B, H, W, C, ks, stride, pad, Ho, Wo, (hipStream_t)stream);
+}
+
+int icap_adaptive_avgpool2d_bf16_f32(const unsigned short* x, float* y, int B, int H, int W, int C, int OH, int OW, void* stream) {
+    return adaptive_avgpool2d_bf16_f32(x, y, B, H, W, C, OH, OW, (hipStream_t)stream);
 }
 
 long long icap_resize_normalize_ws_bytes(int B, int H, int Wo) { return resize_normalize_ws_bytes(B, H, Wo); }

@@ -31,6 +31,7 @@ struct GemmBf16Params {
     int* amax_idx;          // their column indices (first index on ties)
     // CONV kernels only: x is an NHWC image [B][H][W][Cin], row m = (b, oh, ow), k = ((kh * KW) + kw) * Cin + c
     int H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo, KHW;
+    int y16, res16;         // y is stored / residual is read as bf16 [M][N] (activations kept in bf16 between layers)
 };
 
 constexpr int GB16_BK = 32;             // K elements per step (two MFMA K blocks)
@@ -49,7 +50,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // multiple of 32 and taps beyond KH * KW read as zeros.
 template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, int CONV = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) {
-    static_assert(!(CONV && (GATE || A16 || AMAX)), "the convolution form takes fp32 images and has no gate / arg-max");
+    static_assert(!(CONV && (GATE || AMAX)) && !(CONV == 2 && A16), "the convolution form has no gate / arg-max; its 4-channel form reads fp32");
     constexpr int BK = GB16_BK, LDK = GB16_LDK;
     constexpr int TM = BM / 2, TN = BN / 2, RM = TM / 32, RN = TN / 32;
     constexpr int AP = BM / 32;                    // staging passes over A: thread t -> row t/8 + 32 i, floats 4 (t%8) ..
@@ -101,12 +102,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
     const unsigned short* a16_src[A16 ? AP16 : 1];
     const float* g16_src[(A16 && GATE) ? AP16 : 1];
     bool a16_ok[A16 ? AP16 : 1];
+    int a16_ih[(A16 && CONV) ? AP16 : 1], a16_iw[(A16 && CONV) ? AP16 : 1];
     if constexpr (A16) {
 #pragma unroll
         for (int i = 0; i < AP16; ++i) {
             const int m = m0 + b_row + 64 * i;
             a16_ok[i] = (b_row + 64 * i < BM) && m < p.M;
-            a16_src[i] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)(a16_ok[i] ? m : 0) * p.K;
+            if constexpr (CONV) {
+                const int mm = a16_ok[i] ? m : 0;
+                const int b = mm / (p.Ho * p.Wo), r = mm - b * (p.Ho * p.Wo);
+                const int oh = r / p.Wo, ow = r - oh * p.Wo;
+                a16_ih[i] = oh * p.stride - p.pad_t;
+                a16_iw[i] = ow * p.stride - p.pad_l;
+                a16_src[i] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)b * p.H * p.W * p.Cin;
+            } else {
+                a16_src[i] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)(a16_ok[i] ? m : 0) * p.K;
+            }
             if constexpr (GATE) g16_src[i] = p.gate + (size_t)((a16_ok[i] ? m : 0) / p.hw) * p.K;
         }
     }
@@ -131,8 +142,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
         if constexpr (A16) {
 #pragma unroll
             for (int i = 0; i < AP16; ++i) {
-                const bool ok = a16_ok[i] && kb < p.K;
-                ra16[i] = *reinterpret_cast<const uint4*>(ok ? a16_src[i] + kb : reinterpret_cast<const unsigned short*>(p.x));
+                bool ok = a16_ok[i] && kb < p.K;
+                const unsigned short* src = a16_src[i] + kb;
+                if constexpr (CONV == 1) {
+                    const int ih = a16_ih[i] + c_kh, iw = a16_iw[i] + c_kw;
+                    ok = a16_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    src = a16_src[i] + ((size_t)ih * p.W + iw) * p.Cin + c_c0 + b_k8;
+                }
+                ra16[i] = *reinterpret_cast<const uint4*>(ok ? src : reinterpret_cast<const unsigned short*>(p.x));
                 if constexpr (GATE) {
                     rg16[i][0] = *reinterpret_cast<const float4*>(ok ? g16_src[i] + kb : p.gate);
                     rg16[i][1] = *reinterpret_cast<const float4*>(ok ? g16_src[i] + kb + 4 : p.gate);
@@ -314,11 +331,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
                 v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
                 const size_t o = (size_t)m * p.N + n;
                 if (p.residual) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + o);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    if (p.res16) {
+                        const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.residual) + o);
+                        v.x += __uint_as_float(rr.x << 16); v.y += __uint_as_float(rr.x & 0xffff0000u);
+                        v.z += __uint_as_float(rr.y << 16); v.w += __uint_as_float(rr.y & 0xffff0000u);
+                    } else {
+                        const float4 rr = *reinterpret_cast<const float4*>(p.residual + o);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    }
                 }
                 v.x = act_c<ACT>(v.x); v.y = act_c<ACT>(v.y); v.z = act_c<ACT>(v.z); v.w = act_c<ACT>(v.w);
-                *reinterpret_cast<float4*>(p.y + o) = v;
+                if (p.y16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + o) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+                else *reinterpret_cast<float4*>(p.y + o) = v;
             }
             __syncthreads();
         }
@@ -376,9 +400,15 @@ int linear_bf16_f32(const void* xv, int x_bf16, const unsigned short* w, const f
 // row zero-padded from KH*KW*4 to a multiple of 32 values), fused scale / bias / residual / activation: the dense layers
 // of the ResNet-18 and VGG-16 encoders in bf16 compute mode.
 // cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256, 4 = 256x128 tiles.
-int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale, const float* bias, const float* residual, float* y,
+// io_bf16: bit 0 = x is bf16 (Cin % 32 == 0 only), bit 1 = y is stored as bf16, bit 2 = residual is bf16.
+int conv2d_bf16_f32(const void* xv, const unsigned short* w, const float* scale, const float* bias, const void* resv, void* yv,
                     int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
-                    int cfg, hipStream_t st) {
+                    int io_bf16, int cfg, hipStream_t st) {
+    const float* x = reinterpret_cast<const float*>(xv);
+    const float* residual = reinterpret_cast<const float*>(resv);
+    float* y = reinterpret_cast<float*>(yv);
+    const bool x16 = (io_bf16 & 1) != 0;
+    if (io_bf16 < 0 || io_bf16 > 7 || (x16 && Cin % 32)) { set_error("conv2d_bf16: bad io_bf16 flags %d for Cin=%d", io_bf16, Cin); return ICAP_ERR_ARG; }
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_t < 0 ||
         pad_l < 0 || Ho <= 0 || Wo <= 0) {
         set_error("conv2d_bf16: bad arguments");
@@ -404,7 +434,7 @@ int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale,
         return ICAP_ERR_LIMIT;
     }
     GemmBf16Params p{x, w, scale, bias, residual, nullptr, y, (int)M, Cout, (int)K, 1, act, 0, nullptr, nullptr,
-                     H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo, KH * KW};
+                     H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo, KH * KW, (io_bf16 >> 1) & 1, (io_bf16 >> 2) & 1};
     if (cfg < 0) {
         const long long mt = (M + 127) / 128;
         if (Cout >= 256 && mt * ((Cout + 255) / 256) >= 256) cfg = 3;
@@ -417,6 +447,7 @@ int conv2d_bf16_f32(const float* x, const unsigned short* w, const float* scale,
         p.tiles_n = (p.N + BN - 1) / BN;
         const dim3 grid((unsigned)((long long)((p.M + BM - 1) / BM) * p.tiles_n)), block(256);
         if (Cin == 4) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, false, 2>), grid, block, 0, st, p);
+        else if (x16) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, true, 1>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, false, 1>), grid, block, 0, st, p);
     };
     switch (cfg) {

@@ -357,6 +357,58 @@ int maxpool2d_f32(const float* x, float* y, int B, int H, int W, int C, int KS, 
     return launch_status("maxpool2d");
 }
 
+// bf16 activations (kept between the dense layers in bf16 compute mode): eight channels per lane.  The maximum of bf16
+// values is one of them, so the result is exact.
+__global__ void maxpool_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int H, int W, int C,
+                                    int KS, int stride, int pad, int Ho, int Wo, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*Ho*Wo*(C/8)
+    if (i >= total) return;
+    const int nq = C >> 3;
+    const int cq = (int)(i % nq);
+    long long pix = i / nq;
+    const int wo = (int)(pix % Wo); pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const long long b = pix / Ho;
+    const unsigned short* xb = x + (size_t)b * H * W * C + (cq << 3);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int r = 0; r < KS; ++r) {
+        const int hi = ho * stride - pad + r;
+        if ((unsigned)hi >= (unsigned)H) continue;
+        for (int q = 0; q < KS; ++q) {
+            const int wi = wo * stride - pad + q;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(xb + ((size_t)hi * W + wi) * C);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m[2 * j] = fmaxf(m[2 * j], __uint_as_float(u[j] << 16));
+                m[2 * j + 1] = fmaxf(m[2 * j + 1], __uint_as_float(u[j] & 0xffff0000u));
+            }
+        }
+    }
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (__float_as_uint(m[2 * j]) >> 16) | (__float_as_uint(m[2 * j + 1]) & 0xffff0000u);
+    *reinterpret_cast<uint4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * C + (cq << 3)) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+int maxpool2d_bf16(const unsigned short* x, unsigned short* y, int B, int H, int W, int C, int KS, int stride, int pad, int Ho, int Wo,
+                   hipStream_t st) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || KS <= 0 || stride <= 0 || pad < 0 || Ho <= 0 || Wo <= 0) {
+        set_error("maxpool2d_bf16: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (C % 8 || !aligned16(x) || !aligned16(y)) { set_error("maxpool2d_bf16: C %% 8 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
+    if (pad * 2 > KS) { set_error("maxpool2d_bf16: pad larger than half the window"); return ICAP_ERR_ARG; }
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) { set_error("maxpool2d_bf16: too large"); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(maxpool_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, H, W, C, KS, stride, pad, Ho, Wo, total);
+    return launch_status("maxpool2d_bf16");
+}
+
 // ---------------------------------------------------------------- average pooling
 // Adaptive average pooling NHWC -> [B, OH, OW, C] with torch's window rule
 // start = floor(i*H/OH), end = ceil((i+1)*H/OH).  OH = OW = 1 is global pooling.
@@ -382,6 +434,45 @@ __global__ void adaptive_avgpool_kernel(const float* __restrict__ x, float* __re
     const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
     s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
     *reinterpret_cast<float4*>(y + (((size_t)b * OH + oh) * OW + ow) * C + (cq << 2)) = s;
+}
+
+// bf16 input, fp32 output (the last activation of a bf16-stored encoder becomes the fp32 feature vector here)
+__global__ void adaptive_avgpool_bf16_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int H, int W, int C, int OH,
+                                             int OW, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*OH*OW*(C/4)
+    if (i >= total) return;
+    const int nq = C >> 2;
+    const int cq = (int)(i % nq);
+    long long pix = i / nq;
+    const int ow = (int)(pix % OW); pix /= OW;
+    const int oh = (int)(pix % OH);
+    const long long b = pix / OH;
+    const int h0 = (oh * H) / OH, h1 = ((oh + 1) * H + OH - 1) / OH;
+    const int w0 = (ow * W) / OW, w1 = ((ow + 1) * W + OW - 1) / OW;
+    const unsigned short* xb = x + (size_t)b * H * W * C + (cq << 2);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = h0; h < h1; ++h)
+        for (int w_ = w0; w_ < w1; ++w_) {
+            const uint2 v = *reinterpret_cast<const uint2*>(xb + ((size_t)h * W + w_) * C);
+            s.x += __uint_as_float(v.x << 16); s.y += __uint_as_float(v.x & 0xffff0000u);
+            s.z += __uint_as_float(v.y << 16); s.w += __uint_as_float(v.y & 0xffff0000u);
+        }
+    const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+    s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+    *reinterpret_cast<float4*>(y + (((size_t)b * OH + oh) * OW + ow) * C + (cq << 2)) = s;
+}
+
+int adaptive_avgpool2d_bf16_f32(const unsigned short* x, float* y, int B, int H, int W, int C, int OH, int OW, hipStream_t st) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) {
+        set_error("adaptive_avgpool2d_bf16: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (C % 4 || !aligned16(x) || !aligned16(y)) { set_error("adaptive_avgpool2d_bf16: C %% 4 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
+    const long long total = (long long)B * OH * OW * (C / 4);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) { set_error("adaptive_avgpool2d_bf16: too large"); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(adaptive_avgpool_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, H, W, C, OH, OW, total);
+    return launch_status("adaptive_avgpool2d_bf16");
 }
 
 int adaptive_avgpool2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, hipStream_t st) {

@@ -59,12 +59,17 @@ def pointwise_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=N
     return conv2d(x, w, scale, bias, residual=residual, gate=gate, act=act)
 
 
-def dense_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None, *, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE):
+def dense_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None, *, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE,
+               out_bf16=False):
     """KH x KW convolution (conv2d's arguments): the fp32 implicit-GEMM kernel, or - in bf16 compute mode and for
-    Cin % 32 == 0 (or the 4-channel padded image), Cout % 4 == 0 - icap_conv2d_bf16_f32 with a cached bf16 copy of the weight."""
+    Cin % 32 == 0 (or the 4-channel padded image), Cout % 4 == 0 - icap_conv2d_bf16_f32 with a cached bf16 copy of the
+    weight.  In that mode x and residual may be bf16 tensors and out_bf16 asks for a bf16 result (activations kept in
+    bf16 from layer to layer); the fp32 kernel takes and gives fp32 only."""
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     if not (COMPUTE_DTYPE == "bf16" and (Cin % 32 == 0 or Cin == 4) and Cout % 4 == 0):
+        if out_bf16 or x.dtype != torch.float32 or (residual is not None and residual.dtype != torch.float32):
+            raise IcapError("dense_conv: bf16 tensors need the bf16 kernel (bf16 mode, Cin % 32 == 0, Cout % 4 == 0)")
         return conv2d(x, w, scale, bias, residual=residual, stride=stride, pad=pad, act=act)
     w16 = w16_cache.get(key)
     if w16 is None:
@@ -76,15 +81,26 @@ def dense_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None,
     pt, pb, pl, pr = pad
     Ho = conv_out_size(H, KH, stride, pt, pb)
     Wo = conv_out_size(W, KW, stride, pl, pr)
-    out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    x16 = x.dtype == torch.bfloat16
+    r16 = residual is not None and residual.dtype == torch.bfloat16
+    if x16 and Cin % 32:
+        raise IcapError("dense_conv: a bf16 input needs Cin % 32 == 0")
+    out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     if residual is not None and residual.numel() != out.numel():
         raise IcapError("dense_conv: residual has the wrong size")
-    span = _Span("conv2d_bf16", (B, H, W, Cin, Cout, KH, stride, Ho, Wo, residual is not None))
-    N.check(N.load().icap_conv2d_bf16_f32(_ck(x, "x"), _ck(w16, "w", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
-                                          _ck(residual, "residual"), _ck(out, "out"), B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo,
-                                          act, -1, _stream()), "conv2d_bf16")
+    span = _Span("conv2d_bf16", (B, H, W, Cin, Cout, KH, stride, Ho, Wo, residual is not None, x16, bool(out_bf16)))
+    N.check(N.load().icap_conv2d_bf16_f32(_ck(x, "x", x.dtype if x16 else torch.float32), _ck(w16, "w", torch.bfloat16), _ck(scale, "scale"),
+                                          _ck(bias, "bias"), _ck(residual, "residual", torch.bfloat16 if r16 else torch.float32),
+                                          _ck(out, "out", out.dtype), B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo, act,
+                                          int(x16) | (int(bool(out_bf16)) << 1) | (int(r16) << 2), -1, _stream()), "conv2d_bf16")
     span.done()
     return out
+
+
+def bf16_storage_ok(cin: int, cout: int) -> bool:
+    """True when dense_conv can hand a bf16 [.., cout] result to the next dense layer / pooling (bf16 mode, channel counts
+    the bf16 kernels take)."""
+    return COMPUTE_DTYPE == "bf16" and (cin % 32 == 0 or cin == 4) and cout % 32 == 0
 
 
 def bf16_activations_ok(cin: int, cout: int) -> bool:
@@ -306,6 +322,11 @@ def maxpool2d(x, ks, stride, pad):
     B, H, W, Cc = x.shape
     Ho = conv_out_size(H, ks, stride, pad, pad)
     Wo = conv_out_size(W, ks, stride, pad, pad)
+    if x.dtype == torch.bfloat16:       # activations kept in bf16 between the dense layers (bf16 compute mode)
+        y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.bfloat16)
+        N.check(N.load().icap_maxpool2d_bf16(_ck(x, "x", torch.bfloat16), _ck(y, "y", torch.bfloat16), B, H, W, Cc, ks, stride, pad, Ho, Wo,
+                                             _stream()), "maxpool2d")
+        return y
     y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
     N.check(N.load().icap_maxpool2d_f32(_ck(x, "x"), _ck(y, "y"), B, H, W, Cc, ks, stride, pad, Ho, Wo, _stream()), "maxpool2d")
     return y
@@ -314,6 +335,10 @@ def maxpool2d(x, ks, stride, pad):
 def adaptive_avgpool2d(x, oh, ow):
     B, H, W, Cc = x.shape
     y = torch.empty((B, oh, ow, Cc), device=x.device, dtype=torch.float32)
+    if x.dtype == torch.bfloat16:       # bf16 in, fp32 out
+        N.check(N.load().icap_adaptive_avgpool2d_bf16_f32(_ck(x, "x", torch.bfloat16), _ck(y, "y"), B, H, W, Cc, oh, ow, _stream()),
+                "adaptive_avgpool2d")
+        return y
     N.check(N.load().icap_adaptive_avgpool2d_f32(_ck(x, "x"), _ck(y, "y"), B, H, W, Cc, oh, ow, _stream()), "adaptive_avgpool2d")
     return y
 

@@ -97,6 +97,14 @@ def _device_tables(in_size: int, out_size: int, dev):
     return t
 
 
+def _mean_std(mean, std, dev):
+    key = ("mean_std", mean, std, str(dev))
+    t = _DEVICE_TABLES.get(key)
+    if t is None:
+        t = _DEVICE_TABLES[key] = torch.tensor(list(mean) + list(std), dtype=torch.float32).to(dev)
+    return t
+
+
 def resize_normalize(u8_nhwc, size: int = 224, layout: str = "nchw", mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
     """uint8 [B, H, W, 3] (or [H, W, 3]) decoded RGB pixels, all of one size, on the HIP device (a numpy array / CPU
     tensor is copied there) -> fp32 [B, 3, size, size] (``layout="nchw"``, the reference's tensor) or [B, size, size, 4]
@@ -118,7 +126,7 @@ def resize_normalize(u8_nhwc, size: int = 224, layout: str = "nchw", mean=IMAGEN
     dev = t.device
     kx, bx, ksx = _device_tables(W, size, dev)
     ky, by, ksy = _device_tables(H, size, dev)
-    ms = torch.tensor(list(mean) + list(std), dtype=torch.float32).to(dev)
+    ms = _mean_std(tuple(mean), tuple(std), dev)
     lib = N.load()
     tmp = torch.empty(lib.icap_resize_normalize_ws_bytes(B, H, size), device=dev, dtype=torch.uint8)
     out = torch.empty((B, 3, size, size) if layout == "nchw" else (B, size, size, 4), device=dev, dtype=torch.float32)

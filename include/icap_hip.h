@@ -163,14 +163,22 @@ int icap_linear_bf16_f32(const void* x, int x_bf16, const unsigned short* w_bf16
 int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* stream);
 
 /* bf16-product form of icap_conv2d_f32 for the dense KH x KW convolutions of the ResNet-18 / VGG-16 encoders
- * (seq2seqbasic.py:19-35: torchvision conv3x3 + BN + ReLU, residual add): x [B][H][W][Cin] fp32 NHWC with Cin % 32 == 0,
+ * (seq2seqbasic.py:19-35: torchvision conv3x3 + BN + ReLU, residual add): x [B][H][W][Cin] NHWC with Cin % 32 == 0,
  * w_bf16 [Cout][KH][KW][Cin] from icap_to_bf16_f32 - or Cin == 4 (the channel-padded RGB image of the first layer) with
- * every weight row zero-padded from KH*KW*4 to the next multiple of 32 values - fp32 accumulation, y = act(conv * scale + bias (+ residual)) fp32
- * [B][Ho][Wo][Cout]; taps outside the image are zeros (pad_t / pad_l; bottom / right padding follows from Ho / Wo).
- * cfg: -1 = by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256, 4 = 256x128 tiles. */
-int icap_conv2d_bf16_f32(const float* x, const unsigned short* w_bf16, const float* scale, const float* bias, const float* residual,
-                         float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
-                         int Wo, int act, int cfg, void* stream);
+ * every weight row zero-padded from KH*KW*4 to the next multiple of 32 values - fp32 accumulation,
+ * y = act(conv * scale + bias (+ residual)) [B][Ho][Wo][Cout]; taps outside the image are zeros (pad_t / pad_l; bottom /
+ * right padding follows from Ho / Wo).  Tensors are fp32 unless io_bf16 says otherwise: bit 0 = x is bf16 (Cin % 32 == 0
+ * only), bit 1 = y is stored as bf16 (round to nearest even), bit 2 = residual is bf16 - activations kept in bf16 from
+ * one layer to the next.  cfg: -1 = by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256, 4 = 256x128 tiles. */
+int icap_conv2d_bf16_f32(const void* x, const unsigned short* w_bf16, const float* scale, const float* bias, const void* residual,
+                         void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
+                         int Wo, int act, int io_bf16, int cfg, void* stream);
+
+/* icap_maxpool2d_f32 / icap_adaptive_avgpool2d_f32 (torchvision MaxPool2d, AdaptiveAvgPool2d: seq2seqbasic.py:21-35) for
+ * activations stored in bf16: max pooling bf16 -> bf16 (exact; C % 8 == 0), average pooling bf16 -> fp32 (C % 4 == 0). */
+int icap_maxpool2d_bf16(const unsigned short* x, unsigned short* y, int B, int H, int W, int C, int ks, int stride, int pad, int Ho,
+                        int Wo, void* stream);
+int icap_adaptive_avgpool2d_bf16_f32(const unsigned short* x, float* y, int B, int H, int W, int C, int OH, int OW, void* stream);
 
 /* icap_linear_bf16_f32 (no residual / gate / activation) whose epilogue also writes arg-max partials: per row and
  * 128-column tile the maximum and its column, part_val / part_idx [M][icap_linear_bf16_argmax_parts(N)], consumed by

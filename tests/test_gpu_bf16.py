@@ -208,3 +208,49 @@ def test_dense_encoders_bf16_mode_track_fp32(bf16_mode, kind):
     f16 = enc(imgs).clone()
     assert not torch.equal(f32, f16)
     assert float((f32 - f16).abs().max()) <= 1e-2 * float(f32.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,stride,res", [(2, 14, 14, 64, 64, 3, 1, True), (3, 9, 11, 32, 160, 3, 2, False),
+                                                         (1, 7, 7, 512, 512, 3, 1, True), (2, 28, 28, 128, 256, 1, 2, False)])
+def test_dense_conv_bf16_storage(bf16_mode, B, H, W, Cin, Cout, K, stride, res):
+    """bf16 input / residual / result tensors: same arithmetic as with fp32 tensors holding the same (bf16-representable)
+    values, the result rounded to nearest even on the store."""
+    ops = bf16_mode
+    ops.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(B * 10 + Cin)
+    pad = (K // 2,) * 4
+    x16 = torch.randn(B, H, W, Cin, generator=g).to(D).to(torch.bfloat16)
+    w = (torch.randn(Cout, K, K, Cin, generator=g) * (Cin * K * K) ** -0.5).to(D)
+    sc, bi = (torch.rand(Cout, generator=g) + 0.5).to(D), (torch.randn(Cout, generator=g) * 0.1).to(D)
+    Ho, Wo = ops.conv_out_size(H, K, stride, pad[0], pad[1]), ops.conv_out_size(W, K, stride, pad[2], pad[3])
+    r16 = torch.randn(B, Ho, Wo, Cout, generator=g).to(D).to(torch.bfloat16) if res else None
+    cache = {}
+    ref = ops.dense_conv(x16.float(), w, cache, "k", sc, bi, residual=r16.float() if res else None, stride=stride, pad=pad, act=ops.ACT_RELU)
+    y_f = ops.dense_conv(x16, w, cache, "k", sc, bi, residual=r16, stride=stride, pad=pad, act=ops.ACT_RELU)
+    assert y_f.dtype == torch.float32 and torch.equal(y_f, ref)
+    y_h = ops.dense_conv(x16, w, cache, "k", sc, bi, residual=r16, stride=stride, pad=pad, act=ops.ACT_RELU, out_bf16=True)
+    assert y_h.dtype == torch.bfloat16 and torch.equal(y_h, ref.to(torch.bfloat16))
+    y_m = ops.dense_conv(x16.float(), w, cache, "k", sc, bi, residual=r16, stride=stride, pad=pad, act=ops.ACT_RELU, out_bf16=True)
+    assert torch.equal(y_m, y_h)
+    ops.set_compute_dtype("f32")
+    with pytest.raises(ops.IcapError):
+        ops.dense_conv(x16, w, {}, "k", sc, bi, stride=stride, pad=pad)
+
+
+def test_pooling_of_bf16_activations(bf16_mode):
+    import torch.nn.functional as F
+    ops = bf16_mode
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 13, 17, 64, generator=g).to(D).to(torch.bfloat16)
+    for ks, st, pad in ((2, 2, 0), (3, 2, 1)):
+        y = ops.maxpool2d(x, ks, st, pad)
+        ref = F.max_pool2d(x.float().permute(0, 3, 1, 2), ks, st, pad).permute(0, 2, 3, 1)
+        assert y.dtype == torch.bfloat16 and torch.equal(y.float(), ref)
+    a = ops.adaptive_avgpool2d(x, 1, 1)
+    assert a.dtype == torch.float32
+    torch.testing.assert_close(a.view(3, 64), x.float().mean((1, 2)), rtol=1e-5, atol=1e-6)
+    x7 = torch.randn(2, 7, 7, 32, generator=g).to(D).to(torch.bfloat16)
+    assert torch.equal(ops.adaptive_avgpool2d(x7, 7, 7), x7.float())                  # the bf16 -> fp32 step of the VGG trunk
+    a2 = ops.adaptive_avgpool2d(x, 7, 7)
+    ref2 = F.adaptive_avg_pool2d(x.float().permute(0, 3, 1, 2), (7, 7)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(a2, ref2, rtol=1e-5, atol=1e-6)

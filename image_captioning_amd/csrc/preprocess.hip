@@ -84,6 +84,97 @@ __global__ __launch_bounds__(256) void resize_v_normalize_kernel(const unsigned*
     }
 }
 
+// Fast forms used when the sizes allow (anything else takes the two kernels above).
+//
+// Horizontal pass, one workgroup per image row: the row's bytes are copied to LDS with coalesced 32-bit loads (the row
+// starts at an arbitrary byte, so the copy starts at the aligned word below it), then each thread filters one or more
+// output pixels from LDS.  rows = B * H; needs 3 * W + 7 bytes of LDS.
+__global__ __launch_bounds__(256) void resize_h_row_kernel(const unsigned char* __restrict__ src, const int* __restrict__ kx,
+                                                           const int* __restrict__ bx, unsigned* __restrict__ tmp, int W, int Wo,
+                                                           int ksx, long long total_bytes) {
+    extern __shared__ unsigned row_lds[];
+    const long long row = blockIdx.x;
+    const long long off = row * W * 3;
+    const int shift = (int)(off & 3);
+    const long long base = off - shift;
+    const int nwords = (shift + 3 * W + 3) >> 2;
+    const unsigned* src32 = reinterpret_cast<const unsigned*>(src + base);
+    for (int i = threadIdx.x; i < nwords; i += 256) {
+        unsigned v;
+        if (base + 4LL * i + 4 <= total_bytes) {
+            v = src32[i];
+        } else {            // the last word of the whole buffer: never read past its end
+            v = 0;
+            for (int j = 0; j < 4; ++j)
+                if (base + 4LL * i + j < total_bytes) v |= (unsigned)src[base + 4LL * i + j] << (8 * j);
+        }
+        row_lds[i] = v;
+    }
+    __syncthreads();
+    const unsigned char* rb = reinterpret_cast<const unsigned char*>(row_lds) + shift;
+    for (int xo = threadIdx.x; xo < Wo; xo += 256) {
+        int x0 = bx[2 * xo], n = bx[2 * xo + 1];
+        n = n < 0 ? 0 : (n > ksx ? ksx : (n > W ? W : n));
+        x0 = x0 < 0 ? 0 : (x0 > W - n ? W - n : x0);
+        const unsigned char* s = rb + 3 * x0;
+        const int* k = kx + (long long)xo * ksx;
+        int r = 1 << (RS_PREC - 1), g = r, b = r;
+        for (int t = 0; t < n; ++t) {
+            const int w = k[t];
+            r += (int)s[3 * t] * w;
+            g += (int)s[3 * t + 1] * w;
+            b += (int)s[3 * t + 2] * w;
+        }
+        tmp[row * Wo + xo] = rs_clip8(r) | (rs_clip8(g) << 8) | (rs_clip8(b) << 16);
+    }
+}
+
+// Vertical pass + normalisation, four output pixels of one row per thread (Wo % 4 == 0): 16-byte loads of the packed
+// intermediate, 16-byte stores.  grid = (Ho * Wo / 4 / 256 rounded up, B).
+__global__ __launch_bounds__(256) void resize_v4_normalize_kernel(const unsigned* __restrict__ tmp, const int* __restrict__ ky,
+                                                                  const int* __restrict__ by, const float* __restrict__ mean_std,
+                                                                  float* __restrict__ out, int H, int Ho, int Wo, int ksy, int layout) {
+    const int wq = Wo >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Ho * wq) return;
+    const int yo = idx / wq, x4 = (idx - yo * wq) << 2;
+    const long long bimg = blockIdx.y;
+    int y0 = by[2 * yo], n = by[2 * yo + 1];
+    n = n < 0 ? 0 : (n > ksy ? ksy : (n > H ? H : n));
+    y0 = y0 < 0 ? 0 : (y0 > H - n ? H - n : y0);
+    const unsigned* s = tmp + ((bimg * H + y0) * Wo + x4);
+    const int* k = ky + (long long)yo * ksy;
+    int acc[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 1 << (RS_PREC - 1);
+    for (int t = 0; t < n; ++t) {
+        const uint4 p = *reinterpret_cast<const uint4*>(s + (long long)t * Wo);
+        const int w = k[t];
+        const unsigned u[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[j][0] += (int)(u[j] & 255u) * w;
+            acc[j][1] += (int)((u[j] >> 8) & 255u) * w;
+            acc[j][2] += (int)((u[j] >> 16) & 255u) * w;
+        }
+    }
+    float f[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[j][c] = ((float)rs_clip8(acc[j][c]) / 255.0f - mean_std[c]) / mean_std[3 + c];
+    if (layout == 0) {
+        const long long plane = (long long)Ho * Wo;
+        float* o = out + bimg * 3 * plane + (long long)yo * Wo + x4;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(o + c * plane) = make_float4(f[0][c], f[1][c], f[2][c], f[3][c]);
+    } else {
+        float4* o = reinterpret_cast<float4*>(out) + (bimg * Ho + yo) * Wo + x4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = make_float4(f[j][0], f[j][1], f[j][2], 0.f);
+    }
+}
+
 long long resize_normalize_ws_bytes(int B, int H, int Wo) { return (long long)B * H * Wo * 4; }
 
 // src [B][H][W][3] uint8; kx [Wo][ksx], bx [Wo][2], ky [Ho][ksy], by [Ho][2] int32; mean_std: 3 means then 3 stds;
@@ -100,9 +191,19 @@ int resize_normalize_u8_f32(const unsigned char* src, int B, int H, int W, const
     const long long n1 = (long long)B * H * Wo, n2 = (long long)B * Ho * Wo;
     const long long g1 = (n1 + 255) / 256, g2 = (n2 + 255) / 256;
     if (g1 > 0x7fffffffLL || g2 > 0x7fffffffLL) { set_error("resize_normalize: too large"); return ICAP_ERR_LIMIT; }
-    hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)g1), dim3(256), 0, st, src, kx, bx, tmp, W, Wo, ksx, (long long)B * H);
-    hipLaunchKernelGGL(resize_v_normalize_kernel, dim3((unsigned)g2), dim3(256), 0, st, tmp, ky, by, mean_std, out, H, Ho, Wo, ksy,
-                       layout, n2);
+    const long long rows = (long long)B * H;
+    const size_t row_lds = (size_t)(3LL * W + 7) / 4 * 4 + 4;
+    if (row_lds <= 48 * 1024 && rows <= 0x7fffffffLL && (reinterpret_cast<uintptr_t>(src) & 3) == 0)
+        hipLaunchKernelGGL(resize_h_row_kernel, dim3((unsigned)rows), dim3(256), row_lds, st, src, kx, bx, tmp, W, Wo, ksx, rows * W * 3);
+    else
+        hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)g1), dim3(256), 0, st, src, kx, bx, tmp, W, Wo, ksx, rows);
+    // the NCHW planes start at multiples of Ho * Wo floats: 16-byte stores need that product (and out) aligned as well
+    if (Wo % 4 == 0 && B <= 65535 && aligned16(out) && aligned16(tmp))
+        hipLaunchKernelGGL(resize_v4_normalize_kernel, dim3((unsigned)(((long long)Ho * (Wo / 4) + 255) / 256), (unsigned)B), dim3(256), 0,
+                           st, tmp, ky, by, mean_std, out, H, Ho, Wo, ksy, layout);
+    else
+        hipLaunchKernelGGL(resize_v_normalize_kernel, dim3((unsigned)g2), dim3(256), 0, st, tmp, ky, by, mean_std, out, H, Ho, Wo, ksy,
+                           layout, n2);
     return launch_status("resize_normalize");
 }
 

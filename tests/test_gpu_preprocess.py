@@ -36,7 +36,8 @@ def test_kernel_reproduces_the_fixture_bit_for_bit():
         assert zlib.crc32(u8.tobytes()) == int(g[f"rand_{h}x{w}_crc"])
 
 
-@pytest.mark.parametrize("B,h,w,size", [(5, 169, 274, 224), (3, 61, 47, 256), (2, 512, 300, 224), (1, 224, 224, 224)])
+@pytest.mark.parametrize("B,h,w,size", [(5, 169, 274, 224), (3, 61, 47, 256), (2, 512, 300, 224), (1, 224, 224, 224),
+                                        (2, 40, 33, 225), (3, 7, 5, 30), (1, 20, 17000, 64)])   # odd sizes / very wide rows: the general kernels
 def test_kernel_matches_the_oracle_batched_and_in_both_layouts(B, h, w, size):
     rng = np.random.default_rng(B * 1000 + h)
     a = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)

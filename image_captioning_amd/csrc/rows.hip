@@ -364,34 +364,52 @@ int mha_core_f32(const float* q, const float* k, const float* v, float* out, int
 
 // ---------------------------------------------------------------- Bahdanau additive attention
 // score[i][j] = a_b + sum_a a_w[a] * tanh(u[j][a] + w[i][a]);  alpha[i][:] = softmax_j(score[i][:]);
-// context[i][:] = sum_j alpha[i][j] * feat[j][:].   One workgroup per query i.
+// context[i][:] = sum_j alpha[i][j] * feat[j][:].   One workgroup of 16 waves per query i: a wave scores four keys at a
+// time (lanes over a, independent accumulators so the loads of all four are in flight together); the context sum over j
+// is split four ways across the workgroup and combined through LDS in a fixed order.
 constexpr int BAH_MAX_B = 4096;
+constexpr int BAH_THREADS = 1024;
 
-__global__ __launch_bounds__(256) void bahdanau_attention_kernel(
+__global__ __launch_bounds__(BAH_THREADS) void bahdanau_attention_kernel(
     const float* __restrict__ u, const float* __restrict__ w, const float* __restrict__ a_w, float a_b,
     const float* __restrict__ feat, float* __restrict__ alpha, float* __restrict__ context, int B, int A, int E) {
     __shared__ float sc[BAH_MAX_B];
-    __shared__ float redv[4];
+    __shared__ float redv[16];
+    __shared__ float part[4][256];
     const int i = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* wi = w + (size_t)i * A;
-    for (int j = wave; j < B; j += 4) {
-        const float* uj = u + (size_t)j * A;
-        float s = 0.f;
-        for (int a = lane; a < A; a += 64) s = fmaf(a_w[a], tanhf(uj[a] + wi[a]), s);
-        s = wave_sum(s);
-        if (lane == 0) sc[j] = s + a_b;
+    for (int j0 = wave; j0 < B; j0 += 64) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int a = lane; a < A; a += 64) {
+            const float wa = wi[a], aw = a_w[a];
+            float uv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + 16 * q;
+                uv[q] = u[(size_t)(j < B ? j : j0) * A + a];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] = fmaf(aw, tanhf(uv[q] + wa), s[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t = wave_sum(s[q]);
+            if (lane == 0 && j0 + 16 * q < B) sc[j0 + 16 * q] = t + a_b;
+        }
     }
     __syncthreads();
     float m = -INFINITY;
-    for (int j = threadIdx.x; j < B; j += 256) m = fmaxf(m, sc[j]);
+    for (int j = tid; j < B; j += BAH_THREADS) m = fmaxf(m, sc[j]);
     m = wave_max(m);
     if (lane == 0) redv[wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
+    m = redv[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, redv[k]);
     __syncthreads();
     float l = 0.f;
-    for (int j = threadIdx.x; j < B; j += 256) {
+    for (int j = tid; j < B; j += BAH_THREADS) {
         const float p = expf(sc[j] - m);
         sc[j] = p;
         l += p;
@@ -399,17 +417,30 @@ __global__ __launch_bounds__(256) void bahdanau_attention_kernel(
     l = wave_sum(l);
     if (lane == 0) redv[wave] = l;
     __syncthreads();
-    const float inv = 1.0f / (((redv[0] + redv[1]) + redv[2]) + redv[3]);
-    for (int j = threadIdx.x; j < B; j += 256) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += redv[k];
+    const float inv = 1.0f / tot;
+    for (int j = tid; j < B; j += BAH_THREADS) {
         const float p = sc[j] * inv;
         sc[j] = p;
         if (alpha) alpha[(size_t)i * B + j] = p;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < E; e += 256) {
+    // context: thread (q, t) sums keys [q * Bq, (q + 1) * Bq) for column e = e0 + t
+    const int q = tid >> 8, t = tid & 255;
+    const int Bq = (B + 3) / 4, jlo = q * Bq, jhi = (jlo + Bq < B) ? jlo + Bq : B;
+    for (int e0 = 0; e0 < E; e0 += 256) {
+        const int e = e0 + t;
         float c = 0.f;
-        for (int j = 0; j < B; ++j) c = fmaf(sc[j], feat[(size_t)j * E + e], c);
-        context[(size_t)i * E + e] = c;
+        if (e < E) {
+#pragma unroll 8
+            for (int j = jlo; j < jhi; ++j) c = fmaf(sc[j], feat[(size_t)j * E + e], c);
+        }
+        part[q][t] = c;
+        __syncthreads();
+        if (q == 0 && e < E) context[(size_t)i * E + e] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+        __syncthreads();
     }
 }
 
@@ -417,7 +448,7 @@ int bahdanau_attention_f32(const float* u, const float* w, const float* a_w, flo
                            float* alpha, float* context, int B, int A, int E, hipStream_t st) {
     if (!u || !w || !a_w || !feat || !context || B <= 0 || A <= 0 || E <= 0) { set_error("bahdanau_attention: bad arguments"); return ICAP_ERR_ARG; }
     if (B > BAH_MAX_B) { set_error("bahdanau_attention: B=%d exceeds %d", B, BAH_MAX_B); return ICAP_ERR_LIMIT; }
-    hipLaunchKernelGGL(bahdanau_attention_kernel, dim3(B), dim3(256), 0, st, u, w, a_w, a_b, feat, alpha, context, B, A, E);
+    hipLaunchKernelGGL(bahdanau_attention_kernel, dim3(B), dim3(BAH_THREADS), 0, st, u, w, a_w, a_b, feat, alpha, context, B, A, E);
     return launch_status("bahdanau_attention");
 }
 

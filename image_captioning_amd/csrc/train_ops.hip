@@ -572,33 +572,49 @@ int gru_bwd_f32(const float* gi, const float* gh, const float* h_in, const float
 //   dscore[i][j] = alpha[i][j] * (dalpha[i][j] - sum_j' alpha[i][j'] dalpha[i][j']);
 //   dw[i][a] = sum_j dscore[i][j] * a_w[a] * (1 - tanh(u[j][a] + w[i][a])^2);
 //   da_part[i][a] = sum_j dscore[i][j] * tanh(u[j][a] + w[i][a]);   dab_part[i] = sum_j dscore[i][j].
+// Both kernels run 16 waves per workgroup: the long sums over the other batch index are split four ways across the
+// workgroup (thread (q, t) takes a quarter of the range for column t) and combined through LDS in a fixed order, and
+// the inner loops are unrolled so that the loads of several iterations are in flight before the first tanh.
 constexpr int ATT_MAX_B = 1024;
+constexpr int ATT_THREADS = 1024;
 
-__global__ __launch_bounds__(256) void att_bwd_query_kernel(const float* __restrict__ u, const float* __restrict__ w,
-                                                            const float* __restrict__ a_w, const float* __restrict__ alpha,
-                                                            const float* __restrict__ feat, const float* __restrict__ dctx,
-                                                            int B, int A, int E, float* __restrict__ dscore,
-                                                            float* __restrict__ dw, float* __restrict__ da_part,
-                                                            float* __restrict__ dab_part) {
+__global__ __launch_bounds__(ATT_THREADS) void att_bwd_query_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                                    const float* __restrict__ a_w, const float* __restrict__ alpha,
+                                                                    const float* __restrict__ feat, const float* __restrict__ dctx,
+                                                                    int B, int A, int E, float* __restrict__ dscore,
+                                                                    float* __restrict__ dw, float* __restrict__ da_part,
+                                                                    float* __restrict__ dab_part) {
     __shared__ float ds[ATT_MAX_B];
-    __shared__ float red[4];
+    __shared__ float red[16];
+    __shared__ float pw[4][256], pa[4][256];
     const int i = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int j = wave; j < B; j += 4) {
-        float s = 0.f;
-        for (int e = lane; e < E; e += 64) s = fmaf(dctx[(size_t)i * E + e], feat[(size_t)j * E + e], s);
-        s = wave_sum(s);
-        if (lane == 0) ds[j] = s;   // dalpha
+    for (int j0 = wave; j0 < B; j0 += 32) {      // two keys per wave and pass
+        const int j1 = j0 + 16 < B ? j0 + 16 : j0;
+        float s0 = 0.f, s1 = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            const float d = dctx[(size_t)i * E + e];
+            s0 = fmaf(d, feat[(size_t)j0 * E + e], s0);
+            s1 = fmaf(d, feat[(size_t)j1 * E + e], s1);
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) {
+            ds[j0] = s0;   // dalpha
+            if (j0 + 16 < B) ds[j0 + 16] = s1;
+        }
     }
     __syncthreads();
     float dot = 0.f;
-    for (int j = tid; j < B; j += 256) dot += alpha[(size_t)i * B + j] * ds[j];
+    for (int j = tid; j < B; j += ATT_THREADS) dot += alpha[(size_t)i * B + j] * ds[j];
     dot = wave_sum(dot);
     if (lane == 0) red[wave] = dot;
     __syncthreads();
-    dot = ((red[0] + red[1]) + red[2]) + red[3];
+    dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dot += red[k];
     __syncthreads();
     float tot = 0.f;
-    for (int j = tid; j < B; j += 256) {
+    for (int j = tid; j < B; j += ATT_THREADS) {
         const float v = alpha[(size_t)i * B + j] * (ds[j] - dot);
         ds[j] = v;
         dscore[(size_t)i * B + j] = v;
@@ -607,43 +623,86 @@ __global__ __launch_bounds__(256) void att_bwd_query_kernel(const float* __restr
     tot = wave_sum(tot);
     if (lane == 0) red[wave] = tot;
     __syncthreads();
-    if (tid == 0) dab_part[i] = ((red[0] + red[1]) + red[2]) + red[3];
-    for (int a = tid; a < A; a += 256) {
-        const float wi = w[(size_t)i * A + a], aw = a_w[a];
+    if (tid == 0) {
+        float r = 0.f;
+        for (int k = 0; k < 16; ++k) r += red[k];
+        dab_part[i] = r;
+    }
+    const int q = tid >> 8, t = tid & 255;
+    const int Bq = (B + 3) / 4, jlo = q * Bq, jhi = (jlo + Bq < B) ? jlo + Bq : B;
+    for (int a0 = 0; a0 < A; a0 += 256) {
+        const int a = a0 + t;
         float accw = 0.f, acca = 0.f;
-        for (int j = 0; j < B; ++j) {
-            const float t = tanhf(u[(size_t)j * A + a] + wi);
-            accw += ds[j] * (1.f - t * t);
-            acca += ds[j] * t;
+        if (a < A) {
+            const float wi = w[(size_t)i * A + a];
+#pragma unroll 8
+            for (int j = jlo; j < jhi; ++j) {
+                const float th = tanhf(u[(size_t)j * A + a] + wi);
+                accw += ds[j] * (1.f - th * th);
+                acca += ds[j] * th;
+            }
         }
-        dw[(size_t)i * A + a] = accw * aw;
-        da_part[(size_t)i * A + a] = acca;
+        pw[q][t] = accw;
+        pa[q][t] = acca;
+        __syncthreads();
+        if (q == 0 && a < A) {
+            dw[(size_t)i * A + a] = (((pw[0][t] + pw[1][t]) + pw[2][t]) + pw[3][t]) * a_w[a];
+            da_part[(size_t)i * A + a] = ((pa[0][t] + pa[1][t]) + pa[2][t]) + pa[3][t];
+        }
+        __syncthreads();
     }
 }
 
 // Key side, one workgroup per j:  du[j][a] (+)= sum_i dscore[i][j] * a_w[a] * (1 - tanh(u[j][a] + w[i][a])^2);
 //   dfeat[j][e] (+)= sum_i alpha[i][j] * dctx[i][e].
-__global__ __launch_bounds__(256) void att_bwd_key_kernel(const float* __restrict__ u, const float* __restrict__ w,
-                                                          const float* __restrict__ a_w, const float* __restrict__ alpha,
-                                                          const float* __restrict__ dscore, const float* __restrict__ dctx,
-                                                          int B, int A, int E, int accumulate, float* __restrict__ du,
-                                                          float* __restrict__ dfeat) {
+__global__ __launch_bounds__(ATT_THREADS) void att_bwd_key_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                                  const float* __restrict__ a_w, const float* __restrict__ alpha,
+                                                                  const float* __restrict__ dscore, const float* __restrict__ dctx,
+                                                                  int B, int A, int E, int accumulate, float* __restrict__ du,
+                                                                  float* __restrict__ dfeat) {
+    __shared__ float dsj[ATT_MAX_B], alj[ATT_MAX_B];      // column j of dscore and alpha
+    __shared__ float part[4][256];
     const int j = blockIdx.x, tid = threadIdx.x;
-    for (int a = tid; a < A; a += 256) {
-        const float uj = u[(size_t)j * A + a];
-        float acc = 0.f;
-        for (int i = 0; i < B; ++i) {
-            const float t = tanhf(uj + w[(size_t)i * A + a]);
-            acc += dscore[(size_t)i * B + j] * (1.f - t * t);
-        }
-        const size_t o = (size_t)j * A + a;
-        du[o] = (accumulate ? du[o] : 0.f) + acc * a_w[a];
+    for (int i = tid; i < B; i += ATT_THREADS) {
+        dsj[i] = dscore[(size_t)i * B + j];
+        alj[i] = alpha[(size_t)i * B + j];
     }
-    for (int e = tid; e < E; e += 256) {
+    __syncthreads();
+    const int q = tid >> 8, t = tid & 255;
+    const int Bq = (B + 3) / 4, ilo = q * Bq, ihi = (ilo + Bq < B) ? ilo + Bq : B;
+    for (int a0 = 0; a0 < A; a0 += 256) {
+        const int a = a0 + t;
         float acc = 0.f;
-        for (int i = 0; i < B; ++i) acc += alpha[(size_t)i * B + j] * dctx[(size_t)i * E + e];
-        const size_t o = (size_t)j * E + e;
-        dfeat[o] = (accumulate ? dfeat[o] : 0.f) + acc;
+        if (a < A) {
+            const float uj = u[(size_t)j * A + a];
+#pragma unroll 8
+            for (int i = ilo; i < ihi; ++i) {
+                const float th = tanhf(uj + w[(size_t)i * A + a]);
+                acc += dsj[i] * (1.f - th * th);
+            }
+        }
+        part[q][t] = acc;
+        __syncthreads();
+        if (q == 0 && a < A) {
+            const size_t o = (size_t)j * A + a;
+            du[o] = (accumulate ? du[o] : 0.f) + (((part[0][t] + part[1][t]) + part[2][t]) + part[3][t]) * a_w[a];
+        }
+        __syncthreads();
+    }
+    for (int e0 = 0; e0 < E; e0 += 256) {
+        const int e = e0 + t;
+        float acc = 0.f;
+        if (e < E) {
+#pragma unroll 8
+            for (int i = ilo; i < ihi; ++i) acc += alj[i] * dctx[(size_t)i * E + e];
+        }
+        part[q][t] = acc;
+        __syncthreads();
+        if (q == 0 && e < E) {
+            const size_t o = (size_t)j * E + e;
+            dfeat[o] = (accumulate ? dfeat[o] : 0.f) + (((part[0][t] + part[1][t]) + part[2][t]) + part[3][t]);
+        }
+        __syncthreads();
     }
 }
 
@@ -656,8 +715,8 @@ int att_bwd_f32(const float* u, const float* w, const float* a_w, const float* a
         return ICAP_ERR_ARG;
     }
     if (B > ATT_MAX_B) { set_error("att_bwd: batch %d exceeds %d", B, ATT_MAX_B); return ICAP_ERR_LIMIT; }
-    hipLaunchKernelGGL(att_bwd_query_kernel, dim3(B), dim3(256), 0, st, u, w, a_w, alpha, feat, dctx, B, A, E, dscore, dw, da_part, dab_part);
-    hipLaunchKernelGGL(att_bwd_key_kernel, dim3(B), dim3(256), 0, st, u, w, a_w, alpha, dscore, dctx, B, A, E, accumulate, du, dfeat);
+    hipLaunchKernelGGL(att_bwd_query_kernel, dim3(B), dim3(ATT_THREADS), 0, st, u, w, a_w, alpha, feat, dctx, B, A, E, dscore, dw, da_part, dab_part);
+    hipLaunchKernelGGL(att_bwd_key_kernel, dim3(B), dim3(ATT_THREADS), 0, st, u, w, a_w, alpha, dscore, dctx, B, A, E, accumulate, du, dfeat);
     return launch_status("att_bwd");
 }
 

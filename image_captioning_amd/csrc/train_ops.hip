@@ -834,21 +834,53 @@ int mha_bwd_f32(const float* q, const float* k, const float* v, const float* dO,
 }
 
 // ---------------------------------------------------------------- embedding gradient
-// dtable[idx[p]][:] += dy[p][:] for p in order.  Workgroup g owns the table rows with row % gridDim.x == g, so
-// every row is updated by one workgroup in position order: deterministic without atomics.  dtable must be
-// zeroed (or hold the value to accumulate onto) before the call.
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dy, int ldd,
-                                                            int P, int E, int V, float* __restrict__ dtable) {
-    for (int p = 0; p < P; ++p) {
-        const long long t = idx[p];
-        if (t < 0 || t >= V || (int)(t % gridDim.x) != (int)blockIdx.x) continue;
-        for (int e = threadIdx.x; e < E; e += 256) dtable[(size_t)t * E + e] += dy[(size_t)p * ldd + e];
+// dtable[idx[p]][:] += dy[p][:] for p in order.  Workgroup g owns the table rows with row % EMB_GROUPS == g, so
+// every row is updated by one workgroup in position order: deterministic without atomics.  A workgroup looks at 1024
+// positions at a time, compacts the ones it owns into an LDS list (wave ballots keep them in position order) and then
+// applies them one after the other, each thread adding its own columns.  dtable must be zeroed (or hold the value to
+// accumulate onto) before the call.
+constexpr int EMB_GROUPS = 256;      // power of two
+constexpr int EMB_THREADS = 1024;
+
+__global__ __launch_bounds__(EMB_THREADS) void embedding_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dy,
+                                                                    int ldd, int P, int E, int V, float* __restrict__ dtable) {
+    __shared__ int list_p[EMB_THREADS];
+    __shared__ int list_t[EMB_THREADS];
+    __shared__ int wc[EMB_THREADS / 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int c0 = 0; c0 < P; c0 += EMB_THREADS) {
+        const int p = c0 + tid;
+        long long t = -1;
+        if (p < P) t = idx[p];
+        const bool mine = t >= 0 && t < V && (int)(t & (EMB_GROUPS - 1)) == (int)blockIdx.x;
+        const unsigned long long bal = __ballot(mine);
+        if (lane == 0) wc[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < EMB_THREADS / 64; ++k) {
+            const int c = wc[k];
+            off += k < wave ? c : 0;
+            total += c;
+        }
+        if (mine) {
+            const int o = off + __popcll(bal & ((1ull << lane) - 1ull));
+            list_p[o] = p;
+            list_t[o] = (int)t;
+        }
+        __syncthreads();
+        for (int k = 0; k < total; ++k) {
+            const float* src = dy + (size_t)list_p[k] * ldd;
+            float* dst = dtable + (size_t)list_t[k] * E;
+            for (int e = tid; e < E; e += EMB_THREADS) dst[e] += src[e];
+        }
+        __syncthreads();
     }
 }
 
 int embedding_bwd_f32(const long long* idx, const float* dy, int ldd, int P, int E, int V, float* dtable, hipStream_t st) {
     if (!idx || !dy || !dtable || P <= 0 || E <= 0 || V <= 0 || ldd < E) { set_error("embedding_bwd: bad arguments"); return ICAP_ERR_ARG; }
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(256), dim3(256), 0, st, idx, dy, ldd, P, E, V, dtable);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(EMB_GROUPS), dim3(EMB_THREADS), 0, st, idx, dy, ldd, P, E, V, dtable);
     return launch_status("embedding_bwd");
 }
 

@@ -4,6 +4,7 @@
 // gradients, the LSTM cell gradient, the additive-attention gradient and the embedding
 // gradient.  All of them are bound by memory traffic; reductions run in a fixed order
 // (two passes, no atomics), so a training step is reproducible bit for bit.
+#include <initializer_list>
 #include "common.hpp"
 
 namespace icap {
@@ -323,9 +324,42 @@ __global__ __launch_bounds__(256) void scale_bias_act_kernel(const float* __rest
     }
 }
 
+// 16 bytes per lane when every row start and the channel count allow it
+__global__ __launch_bounds__(256) void scale_bias_act_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ s,
+                                                                 const float* __restrict__ b, const float* __restrict__ res,
+                                                                 int ldr, int act, int M, int C4, float* __restrict__ y, int ldy) {
+    const unsigned total = (unsigned)M * (unsigned)C4;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned r = i / (unsigned)C4, c = (i - r * (unsigned)C4) << 2;
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+        const float4 sv = s ? *reinterpret_cast<const float4*>(s + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 bv = b ? *reinterpret_cast<const float4*>(b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = make_float4(act_apply(fmaf(xv.x, sv.x, bv.x), act), act_apply(fmaf(xv.y, sv.y, bv.y), act),
+                               act_apply(fmaf(xv.z, sv.z, bv.z), act), act_apply(fmaf(xv.w, sv.w, bv.w), act));
+        if (res) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + (size_t)r * ldr + c);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        *reinterpret_cast<float4*>(y + (size_t)r * ldy + c) = v;
+    }
+}
+
+static bool vec4_ok(long long M, int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    if (C % 4 || M * (C / 4) >= (1LL << 31)) return false;
+    for (int ld : lds) if (ld % 4) return false;
+    for (const void* p : ptrs) if (p && !aligned16(p)) return false;
+    return true;
+}
+
 int scale_bias_act_f32(const float* x, int ldx, const float* s, const float* b, const float* res, int ldr, int act, int M, int C,
                        float* y, int ldy, hipStream_t st) {
     if (!x || !y || M <= 0 || C <= 0 || ldx < C || ldy < C || (res && ldr < C)) { set_error("scale_bias_act: bad arguments"); return ICAP_ERR_ARG; }
+    if (vec4_ok(M, C, {ldx, ldy, res ? ldr : 0}, {x, y, s, b, res})) {
+        long long vb = ((long long)M * (C / 4) + 255) / 256;
+        if (vb > 16384) vb = 16384;
+        hipLaunchKernelGGL(scale_bias_act_vec_kernel, dim3((unsigned)vb), dim3(256), 0, st, x, ldx, s, b, res, ldr, act, M, C / 4, y, ldy);
+        return launch_status("scale_bias_act");
+    }
     long long blocks = ((long long)M * C + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(scale_bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, s, b, res, ldr, act, M, C, y, ldy);
@@ -352,12 +386,53 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ x, int ldx,
+                                                             const float* __restrict__ s, const float* __restrict__ b,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                             int act, int M, int C4, float* __restrict__ dx, int ldo) {
+    const unsigned total = (unsigned)M * (unsigned)C4;
+    const float inv_m = 1.0f / (float)M;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned r = i / (unsigned)C4, c = (i - r * (unsigned)C4) << 2;
+        const float4 xq = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+        const float4 dq = *reinterpret_cast<const float4*>(dy + (size_t)r * ldd + c);
+        const float xv[4] = {xq.x, xq.y, xq.z, xq.w}, dv[4] = {dq.x, dq.y, dq.z, dq.w};
+        // per-channel parameters as 16-byte loads as well (the channel vectors are 16-byte aligned: checked by the caller)
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 s4 = s ? *reinterpret_cast<const float4*>(s + c) : one;
+        const float4 b4 = b ? *reinterpret_cast<const float4*>(b + c) : zero;
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = dv[k] * act_grad(fmaf(xv[k], sv[k], bv[k]), act);
+        if (mean) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mean + c), r4 = *reinterpret_cast<const float4*>(rstd + c);
+            const float4 g4 = *reinterpret_cast<const float4*>(dgamma + c), e4 = *reinterpret_cast<const float4*>(dbeta + c);
+            const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = o[k] - ev[k] * inv_m - (xv[k] - mv[k]) * rv[k] * gv[k] * inv_m;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] *= sv[k];
+        *reinterpret_cast<float4*>(dx + (size_t)r * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 int bn_act_bwd_f32(const float* dy, int ldd, const float* x, int ldx, const float* s, const float* b, const float* mean,
                    const float* rstd, const float* dgamma, const float* dbeta, int act, int M, int C, float* dx, int ldo,
                    hipStream_t st) {
     if (!dy || !x || !dx || M <= 0 || C <= 0 || ldd < C || ldx < C || ldo < C || (mean && (!rstd || !dgamma || !dbeta))) {
         set_error("bn_act_bwd: bad arguments");
         return ICAP_ERR_ARG;
+    }
+    if (vec4_ok(M, C, {ldd, ldx, ldo}, {dy, x, dx, s, b, mean, rstd, dgamma, dbeta})) {
+        long long vb = ((long long)M * (C / 4) + 255) / 256;
+        if (vb > 16384) vb = 16384;
+        hipLaunchKernelGGL(bn_act_bwd_vec_kernel, dim3((unsigned)vb), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma, dbeta, act, M,
+                           C / 4, dx, ldo);
+        return launch_status("bn_act_bwd");
     }
     long long blocks = ((long long)M * C + 255) / 256;
     if (blocks > 8192) blocks = 8192;

@@ -283,6 +283,12 @@ def image_dot(x, y, B, HW, C, scale=1.0):
 
 
 def dwconv_bwd_data(dy, w, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo):
+    if S == 1 and Ho == H and Wo == W and C % 4 == 0 and dy.is_contiguous():
+        # stride 1: the input gradient is itself a depthwise convolution - of dy with the taps in reverse order and the
+        # padding mirrored - so it runs on the forward strip kernel (no BatchNorm, no activation)
+        dx, _ = ops.dwconv2d(dy.view(B, Ho, Wo, C), w.flip(0).contiguous(), ks=K, stride=1,
+                             pad=(K - 1 - pad_t, pad_t, K - 1 - pad_l, pad_l))
+        return dx.view(B * H * W, C)
     dx = torch.empty(B * H * W, C, device=dy.device, dtype=torch.float32)
     span = _Span("dwconv_bwd_data", (B, H, W, C, K, S, Ho, Wo))
     N.check(N.load().icap_dwconv_bwd_data_f32(dy.data_ptr(), w.data_ptr(), B, H, W, C, K, S, pad_t, pad_l, Ho, Wo, dx.data_ptr(), _stream()),

@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("caption", "train"), default="caption")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="compute dtype of the captioning GEMMs: f32 (default, the reference's), or bf16 products with fp32 "
-                         "accumulation and fp32 tensors in memory (captioning mode only)")
+                    help="compute dtype of the GEMMs: f32 (default, the reference's), or bf16 products with fp32 accumulation and "
+                         "fp32 tensors in memory (training mode: forward GEMMs and input gradients; fp32 weight gradients)")
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the secondary bf16-mode measurement")
     ap.add_argument("--no-train-mode", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--train-batch", type=int, default=256, help="images per step per GPU of the secondary training measurement")
@@ -122,10 +122,15 @@ WORK = {"linear_bf16": lambda s: linear_bf16_work(s), "conv2d_bf16": lambda s: c
 
 
 TRAIN_WORKLOAD = ("transformer_word_level_bahdnau: teacher-forced training step (EfficientNet-B0 train mode + encoder block + "
-                  "Bahdanau LSTMCell decoder, compute_loss, backward, AdamW), fp32 (BASELINE configs[2] names bf16: not built yet)")
+                  "Bahdanau LSTMCell decoder, compute_loss, backward, AdamW)")
+TRAIN_DTYPES = {"f32": "f32",
+                "bf16": "bf16 products in the forward GEMMs and input gradients / f32 accumulation, master weights, activations, "
+                        "weight gradients and optimizer"}
+TRAIN_BF16_TOLERANCE = ("loss within 2e-2, gradients within 0.1 relative L2 (cosine > 0.99) of the f32 step "
+                        "(tests/test_gpu_train_bf16.py)")
 
 
-def build_train_step(torch, dev, rank, B):
+def build_train_step(torch, dev, rank, B, dtype="f32"):
     """The Bahdanau captioner in train mode on `dev` with its Trainer (data-parallel when a process group is up) and one
     synthetic batch -> (model, step)."""
     from image_captioning_amd import transformer_word_level_bahdnau as bah
@@ -138,12 +143,13 @@ def build_train_step(torch, dev, rank, B):
     model.load_state_dict(seeded_state_dict(model, seed=52))
     model = model.to(dev)
     DropoutState.manual_seed(1000 + rank)                             # dropout differs per rank, weights do not
-    trainer = Trainer(model, lr=1e-4, weight_decay=1e-5)              # :191
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-5, dtype=dtype)  # :191
     caps = synthetic_captions(B, CAPTION_LEN, VOCAB, 2, 3, 0, seed=77 + rank).to(dev)
 
     def step():
         return trainer.step(images, caps, 0)
 
+    step.trainer = trainer
     return model, step
 
 
@@ -182,9 +188,27 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": 3,
-            "images_per_step_per_gpu": B, "dtype": "f32", "scaling": "weak", "loss_last_step": float(loss),
-            "workload": TRAIN_WORKLOAD, "parallelism": train_parallelism(model, world)}
+    res = {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": 3,
+           "images_per_step_per_gpu": B, "dtype": "f32", "scaling": "weak", "loss_last_step": float(loss),
+           "workload": TRAIN_WORKLOAD, "parallelism": train_parallelism(model, world)}
+    # the same trainer with bf16 products (BASELINE configs[2] names bf16), same K steps between the same barriers
+    step.trainer.dtype = "bf16"
+    for _ in range(2):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    note(rank, f"train secondary, bf16 products: {steps} steps in {elapsed:.2f} s")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res["bf16"] = {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "dtype": TRAIN_DTYPES["bf16"],
+                   "loss_last_step": float(loss), "tolerance": TRAIN_BF16_TOLERANCE}
+    return res
 
 
 def with_deadline(seconds, on_timeout, fn):
@@ -252,7 +276,7 @@ def main():
     pool = synthetic_images(min(B, 32), seed=1234 + rank)
     images = pool.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
     if train:
-        model, step = build_train_step(torch, dev, rank, B)
+        model, step = build_train_step(torch, dev, rank, B, args.dtype)
     else:
         model = twl.build_model(VOCAB)
         model.load_state_dict(seeded_state_dict(model, seed=52))
@@ -347,7 +371,7 @@ def main():
         dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom_events) / max(len(dom_events), 1)
         flops, byts = WORK[dom["name"]](dom["sig"])
         hbm_t = byts / (HBM_PEAK_GBS * 1e9)
-        mfma_peak = BF16_MFMA_PEAK_TFLOPS if dom["name"] == "linear_bf16" else F32_MFMA_PEAK_TFLOPS
+        mfma_peak = BF16_MFMA_PEAK_TFLOPS if dom["name"] in ("linear_bf16", "conv2d_bf16") else F32_MFMA_PEAK_TFLOPS
         mfma_t = flops / (mfma_peak * 1e12)
         if hbm_t >= mfma_t:
             roof = {"bound": "hbm", "achieved": byts / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
@@ -368,7 +392,7 @@ def main():
             "metric": "captions/sec greedy + train imgs/sec, 224px food imgs, 1/2/4/8 MI355X",
             "value": captions / elapsed, "unit": "imgs/s" if train else "captions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, **({"rehearsal": "gloo, shared devices: not a result"} if args.rehearse else {}), "dtype": "f32" if (train or args.dtype == "f32") else "bf16 products / f32 accumulate / f32 storage except the fused expand+depthwise results (bf16)", "data": "synthetic",
+            "vs_baseline": None, **({"rehearsal": "gloo, shared devices: not a result"} if args.rehearse else {}), "dtype": TRAIN_DTYPES[args.dtype] if train else "f32" if args.dtype == "f32" else "bf16 products / f32 accumulate / f32 storage except the fused expand+depthwise results (bf16)", "data": "synthetic",
             "config": {"workload": workload, "images_per_step_per_gpu": B, "image": "3x224x224 fp32", "caption_tokens": CAPTION_LEN,
                        "vocab": VOCAB, "weights": "seeded random init", "parallelism": par},
             "roofline": roof,

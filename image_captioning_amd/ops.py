@@ -51,6 +51,54 @@ def compute_dtype() -> str:
     return COMPUTE_DTYPE
 
 
+# Training-step state, set for the duration of one forward + backward by `train_step` (training.Trainer.step does).
+# TRAIN_DTYPE "bf16": every Linear / 1x1-convolution product of the step's forward pass and of its input gradients
+# (dX = dY W) multiplies bf16-rounded operands on the bf16 matrix cores with fp32 accumulation; parameters, activations,
+# gradients and optimizer state stay fp32 in memory, and the weight gradients (dW = dY^T X) are fp32 products.
+# _step_cache: per-step copies derived from the weights (bf16 copies, transposed copies), built the first time a
+# weight is used in the step - the LSTM weights are used once per time step - and dropped when the step ends, before
+# the optimizer changes the weights.  An entry keeps its source tensor alive, so an address cannot be re-used by
+# another tensor while the entry exists.
+TRAIN_DTYPE = "f32"
+_step_cache = None
+# GEMMs with fewer rows than this stay on the fp32 kernel in a bf16 step: the per-time-step decoder GEMMs (M = batch) have
+# too few output tiles to fill the chip and run faster on the fp32 kernel's split-K configurations (measured at M = 256:
+# 21.7 us fp32 against 34.8 us bf16 for [256, 2048] x [2048, 512]); the 1x1 convolutions (M = batch x pixels) and the
+# vocabulary projection (M = batch x tokens) are where bf16 pays (2-3.5x on the layers with K >= 192).
+TRAIN_BF16_MIN_ROWS = 1024
+
+
+class train_step:
+    """Context of one training step's forward + backward: `with ops.train_step("bf16"): ...`."""
+
+    def __init__(self, dtype: str = "f32"):
+        if dtype not in ("f32", "bf16"):
+            raise IcapError(f"train_step: unknown dtype {dtype!r}")
+        self.dtype = dtype
+
+    def __enter__(self):
+        global TRAIN_DTYPE, _step_cache
+        self.saved = (TRAIN_DTYPE, _step_cache)
+        TRAIN_DTYPE, _step_cache = self.dtype, {}
+        return self
+
+    def __exit__(self, *exc):
+        global TRAIN_DTYPE, _step_cache
+        TRAIN_DTYPE, _step_cache = self.saved
+        return False
+
+
+def step_cached(kind: str, src: torch.Tensor, make):
+    """make() once per (kind, src) within a training step; outside a step it is simply make()."""
+    if _step_cache is None:
+        return make()
+    key = (kind, src.data_ptr(), tuple(src.shape), src.stride(0))
+    hit = _step_cache.get(key)
+    if hit is None:
+        hit = _step_cache[key] = (src, make())
+    return hit[1]
+
+
 def pointwise_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None, gate=None, act=ACT_NONE):
     """1x1 convolution x [B,H,W,Cin] with w [Cout,1,1,Cin]: the fp32 implicit-GEMM kernel, or - in bf16 compute mode and
     for shapes the bf16 kernel accepts - icap_linear_bf16_f32 with a cached bf16 copy of the weight."""
@@ -217,6 +265,10 @@ def linear(x, w, bias=None, scale=None, act=ACT_NONE, residual=None, out=None):
         out = torch.empty((M, Nn), device=x.device, dtype=torch.float32)
     if residual is not None and residual.numel() != M * Nn:
         raise IcapError("linear: residual has the wrong size")
+    if TRAIN_DTYPE == "bf16" and K % 8 == 0 and Nn % 4 == 0 and M >= TRAIN_BF16_MIN_ROWS:
+        # bf16 training step: same epilogue, bf16 products (the weight's bf16 copy is made once per step)
+        w16 = step_cached("bf16", w, lambda: to_bf16(w))
+        return linear_bf16(x, w16, bias, scale, act=act, residual=residual, out=out)
     span = _Span("linear", (M, K, Nn, residual is not None))
     N.check(_conv_entry((M, 1, 1, K, Nn, 1, 1, 1, 1, 1))(
         _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"), None,

@@ -54,7 +54,8 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, a
     if K % 4 == 0 and Nn % 4 == 0 and a.stride(0) == K and out.stride(0) == Nn and M >= 64:
         # the tuned implicit-GEMM kernel wants the contraction axis of both operands contiguous: a transposed copy of the
         # (small) second operand buys its 60-100 TFLOP/s instead of the k-major staging of the generic backward kernel
-        bt = transpose(b)
+        # (inside a training step the copy is made once per weight, not once per time step)
+        bt = ops.step_cached("transposed", b, lambda: transpose(b))
         return ops.linear(a, bt, residual=out if accumulate else None, out=out)
     ws = _ws(lib.icap_gemm_bwd_ws_floats(M, Nn, K, int(accumulate)), a.device)
     span = _Span("gemm_nn", (M, K, Nn))

@@ -20,6 +20,7 @@ from __future__ import annotations
 import torch
 
 from . import _native as N
+from . import ops
 from .ops import _ck, _stream
 
 
@@ -342,9 +343,13 @@ class Trainer:
     """
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, group=None, bucket_mb=16.0,
-                 loss="compute_loss", overlap=False):
+                 loss="compute_loss", overlap=False, dtype="f32"):
         import torch.distributed as dist
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"Trainer: dtype must be 'f32' or 'bf16', not {dtype!r}")
         self.model = model
+        self.dtype = dtype                   # "bf16": bf16 products in forward and input gradients, fp32 master weights
+                                             # / accumulation / weight gradients / optimizer (ops.train_step)
         self.opt = AdamW(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.reducer = GradientReducer(self.opt, group=group, bucket_mb=bucket_mb, overlap=overlap) if dist.is_available() and dist.is_initialized() else None
         self.loss_kind = loss
@@ -354,12 +359,13 @@ class Trainer:
         self.opt.zero_grad()
         if self.reducer is not None:
             self.reducer.prepare()
-        predictions = self.model(images, captions)
-        if self.loss_kind == "compute_loss":
-            loss = compute_loss(predictions[:, :-1], captions[:, 1:], padding_idx)
-        else:
-            loss = CrossEntropyLoss(ignore_index=padding_idx)(predictions.reshape(-1, predictions.size(-1)), captions.reshape(-1))
-        loss.backward()
+        with ops.train_step(self.dtype):      # per-step weight copies live until backward is done
+            predictions = self.model(images, captions)
+            if self.loss_kind == "compute_loss":
+                loss = compute_loss(predictions[:, :-1], captions[:, 1:], padding_idx)
+            else:
+                loss = CrossEntropyLoss(ignore_index=padding_idx)(predictions.reshape(-1, predictions.size(-1)), captions.reshape(-1))
+            loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()

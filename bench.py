@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="compute dtype of the GEMMs: f32 (default, the reference's), or bf16 products with fp32 accumulation and "
                          "fp32 tensors in memory (training mode: forward GEMMs and input gradients; fp32 weight gradients)")
+    ap.add_argument("--graph", action="store_true",
+                    help="training mode: record the step into a HIP graph (Trainer(graph=True); single GPU, pays at small batches)")
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the secondary bf16-mode measurement")
     ap.add_argument("--no-train-mode", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--train-batch", type=int, default=256, help="images per step per GPU of the secondary training measurement")
@@ -130,7 +132,7 @@ TRAIN_BF16_TOLERANCE = ("loss within 2e-2, gradients within 0.1 relative L2 (cos
                         "(tests/test_gpu_train_bf16.py)")
 
 
-def build_train_step(torch, dev, rank, B, dtype="f32"):
+def build_train_step(torch, dev, rank, B, dtype="f32", graph=False):
     """The Bahdanau captioner in train mode on `dev` with its Trainer (data-parallel when a process group is up) and one
     synthetic batch -> (model, step)."""
     from image_captioning_amd import transformer_word_level_bahdnau as bah
@@ -143,7 +145,7 @@ def build_train_step(torch, dev, rank, B, dtype="f32"):
     model.load_state_dict(seeded_state_dict(model, seed=52))
     model = model.to(dev)
     DropoutState.manual_seed(1000 + rank)                             # dropout differs per rank, weights do not
-    trainer = Trainer(model, lr=1e-4, weight_decay=1e-5, dtype=dtype)  # :191
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-5, dtype=dtype, graph=graph)  # :191
     caps = synthetic_captions(B, CAPTION_LEN, VOCAB, 2, 3, 0, seed=77 + rank).to(dev)
 
     def step():
@@ -276,7 +278,7 @@ def main():
     pool = synthetic_images(min(B, 32), seed=1234 + rank)
     images = pool.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
     if train:
-        model, step = build_train_step(torch, dev, rank, B, args.dtype)
+        model, step = build_train_step(torch, dev, rank, B, args.dtype, args.graph and world == 1)
     else:
         model = twl.build_model(VOCAB)
         model.load_state_dict(seeded_state_dict(model, seed=52))
@@ -313,6 +315,11 @@ def main():
             return ev
         return None
 
+    # --graph: tuning and the dominant-kernel events come from eager steps (a replayed graph makes no traced launches; it
+    # runs the same kernels), then the step is recorded and the timed region replays it
+    graph_mode = train and args.graph and world == 1
+    if graph_mode:
+        step.trainer.graph = False
     note(rank, f"process group and model ready ({'train' if train else 'caption'} mode, batch {B}, world {world})")
     ops.set_autotune(True)      # the first warm-up pass times the tile configurations of every GEMM shape once
     for _ in range(max(args.warmup, 1)):
@@ -322,6 +329,14 @@ def main():
     note(rank, "warm-up and tuning done")
     find_dominant()
     ops.set_trace(dom_trace)
+    if graph_mode:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ops.set_trace(None)
+        step.trainer.graph = True
+        for _ in range(4):          # two eager steps, the recording (with its first replay), one more replay
+            step()
 
     def barrier():
         if world > 1:
@@ -383,7 +398,7 @@ def main():
         roof["avg_launch_ms"] = dom_ms
         if train:
             workload = TRAIN_WORKLOAD
-            par = train_parallelism(model, world)
+            par = train_parallelism(model, world) + (", step replayed from a HIP graph" if args.graph and world == 1 else "")
         else:
             workload = ("transformer_word_level: EfficientNet-B0 encoder + word-level transformer decoder, "
                         "batched greedy captioning (BASELINE configs[1])")

@@ -98,6 +98,7 @@ SIGNATURES = {
     "icap_ce_loss_fwd_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _ll, _i, _p, _p, _p, _p]),
     "icap_ce_loss_bwd_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _ll, _p, _p, _p, _p, _i, _p]),
     "icap_adamw_f32": (_i, [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _f, _p]),
+    "icap_adamw_dev_f32": (_i, [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _p, _i, _f, _p]),
     "icap_gemm_bwd_f32": (_i, [_p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p]),
     "icap_gemm_bwd_ws_floats": (_ll, [_i, _i, _i, _i]),
     "icap_col_reduce_f32": (_i, [_i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "icap_bn_act_bwd_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "icap_axpby_f32": (_i, [_p, _f, _f, _p, _ll, _p]),
     "icap_dropout_f32": (_i, [_p, _f, C.c_ulonglong, C.c_ulonglong, _ll, _ll, _p, _p, _p]),
+    "icap_dropout_dev_f32": (_i, [_p, _f, C.c_ulonglong, C.c_ulonglong, _p, _ll, _ll, _p, _p, _p]),
     "icap_mul_mask_f32": (_i, [_p, _p, _ll, _p, _ll, _p, _p]),
     "icap_ln_train_fwd_f32": (_i, [_p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p]),
     "icap_ln_bwd_f32": (_i, [_p, _p, _p, _p, _p, _f, _i, _i, _p, _p]),

@@ -73,6 +73,7 @@ int ce_loss_fwd_f32(const float*, int, int, int, const long long*, int, int, lon
 int ce_loss_bwd_f32(const float*, int, int, int, const long long*, int, int, long long, const float*, const float*, const float*,
                     float*, int, hipStream_t);
 int adamw_f32(float*, const float*, float*, float*, long long, float, float, float, float, float, int, float, hipStream_t);
+int adamw_dev_f32(float*, const float*, float*, float*, long long, float, float, float, float, float, const int*, int, float, hipStream_t);
 
 int gemm_bwd_f32(const float*, int, int, const float*, int, float*, int, int, int, int, int, float*, hipStream_t);
 long long gemm_bwd_ws_floats(int, int, int, int);
@@ -88,6 +89,8 @@ int bn_act_bwd_f32(const float*, int, const float*, int, const float*, const flo
                    const float*, int, int, int, float*, int, hipStream_t);
 int axpby_f32(const float*, float, float, float*, long long, hipStream_t);
 int dropout_f32(const float*, float, unsigned long long, unsigned long long, long long, long long, float*, float*, hipStream_t);
+int dropout_dev_f32(const float*, float, unsigned long long, unsigned long long, const unsigned long long*, long long, long long, float*, float*,
+                    hipStream_t);
 int mul_mask_f32(const float*, const float*, long long, const float*, long long, float*, hipStream_t);
 int ln_train_fwd_f32(const float*, const float*, const float*, const float*, float, float, int, int, float*, float*, float*, float*,
                      hipStream_t);
@@ -472,6 +475,16 @@ int icap_ce_loss_bwd_f32(const float* logits, int ld, int group_rows, int group_
                          int V, long long ignore_index, const float* row_lse, const float* meta, const float* grad_out,
                          float* dlogits, int ldd, void* stream) {
     return ce_loss_bwd_f32(logits, ld, group_rows, group_stride, targets, R, V, ignore_index, row_lse, meta, grad_out, dlogits, ldd, (hipStream_t)stream);
+}
+
+int icap_adamw_dev_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, const int* step_dev, int step_bias, float grad_scale, void* stream) {
+    return adamw_dev_f32(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, step_bias, grad_scale, (hipStream_t)stream);
+}
+
+int icap_dropout_dev_f32(const float* x, float p, unsigned long long seed, unsigned long long offset, const unsigned long long* offset_base,
+                         long long n, long long group, float* y, float* mask, void* stream) {
+    return dropout_dev_f32(x, p, seed, offset, offset_base, n, group, y, mask, (hipStream_t)stream);
 }
 
 int icap_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

@@ -145,6 +145,53 @@ __global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, cons
     }
 }
 
+// The same update with the step count t = *step_dev + step_bias read from device memory (a launch recorded in a HIP
+// graph keeps its arguments; the counter is what advances between replays).  The bias corrections are computed per
+// lane in double precision, as the host does for the launch-argument form.
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                        float4* __restrict__ m, float4* __restrict__ v, long long n4,
+                                                        float lr, float decay, float b1, float b2, float eps, float grad_scale,
+                                                        const int* __restrict__ step_dev, int step_bias) {
+    const double t = (double)(*step_dev + step_bias);
+    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    const float one_minus_b1 = 1.0f - b1, one_minus_b2 = 1.0f - b2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        float* pa = reinterpret_cast<float*>(&pp);
+        float* ga = reinterpret_cast<float*>(&gg);
+        float* ma = reinterpret_cast<float*>(&mm);
+        float* va = reinterpret_cast<float*>(&vv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gr = ga[k] * grad_scale;
+            float pk = pa[k] * decay;
+            const float mk = ma[k] + (gr - ma[k]) * one_minus_b1;
+            const float vk = va[k] * b2 + gr * gr * one_minus_b2;
+            const float denom = sqrtf(vk) * inv_bc2_sqrt + eps;
+            pk -= step_size * (mk / denom);
+            pa[k] = pk; ma[k] = mk; va[k] = vk;
+        }
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+int adamw_dev_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, const int* step_dev, int step_bias, float grad_scale, hipStream_t st) {
+    if (!p || !g || !m || !v || !step_dev || n <= 0) { set_error("adamw_dev: bad arguments"); return ICAP_ERR_ARG; }
+    if (n % 4 || !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) {
+        set_error("adamw_dev: n %% 4 and 16-byte aligned buffers required");
+        return ICAP_ERR_ALIGN;
+    }
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<float4*>(p),
+                       reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n4,
+                       lr, 1.0f - lr * weight_decay, beta1, beta2, eps, grad_scale, step_dev, step_bias);
+    return launch_status("adamw_dev");
+}
+
 int adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int step, float grad_scale, hipStream_t st) {
     if (!p || !g || !m || !v || n <= 0 || step <= 0) { set_error("adamw: bad arguments"); return ICAP_ERR_ARG; }

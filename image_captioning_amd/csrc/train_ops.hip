@@ -470,6 +470,29 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
 }
 
+// The same with the offset split in two: `offset` (a launch argument) + *offset_base (device memory).  A launch recorded
+// in a HIP graph keeps its arguments for ever; the base is what moves from one replay to the next.
+__global__ __launch_bounds__(256) void dropout_dev_kernel(const float* __restrict__ x, float p, unsigned long long seed,
+                                                          unsigned long long offset, const unsigned long long* __restrict__ offset_base,
+                                                          long long n, long long group, float* __restrict__ y, float* __restrict__ mask) {
+    const float keep = 1.0f / (1.0f - p);
+    const unsigned long long off = offset + *offset_base;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float f = uniform01(seed, off + (unsigned long long)(i / group)) >= p ? keep : 0.f;
+        mask[group > 1 ? i / group : i] = f;
+        y[i] = x[i] * f;
+    }
+}
+
+int dropout_dev_f32(const float* x, float p, unsigned long long seed, unsigned long long offset, const unsigned long long* offset_base,
+                    long long n, long long group, float* y, float* mask, hipStream_t st) {
+    if (!x || !y || !mask || !offset_base || n <= 0 || group <= 0 || !(p >= 0.f && p < 1.f)) { set_error("dropout_dev: bad arguments"); return ICAP_ERR_ARG; }
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dropout_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, p, seed, offset, offset_base, n, group, y, mask);
+    return launch_status("dropout_dev");
+}
+
 int dropout_f32(const float* x, float p, unsigned long long seed, unsigned long long offset, long long n, long long group,
                 float* y, float* mask, hipStream_t st) {
     if (!x || !y || !mask || n <= 0 || group <= 0 || !(p >= 0.f && p < 1.f)) { set_error("dropout: bad arguments"); return ICAP_ERR_ARG; }

@@ -169,12 +169,22 @@ def axpby(x, y, alpha=1.0, beta=1.0):
     return y
 
 
+# While a training step is being recorded into a HIP graph (training.Trainer(graph=True)) this holds a one-element
+# int64 device tensor: the dropout kernels add its value to their offset, and the graph advances it at the end of every
+# replay, so a recorded step draws new masks each time it runs.
+DROPOUT_BASE = None
+
+
 def dropout(x, p, seed, offset, group=1):
     """Returns (y, mask); mask has x.numel() // group entries (0 or 1/(1-p))."""
     _ck(x, "x")
     n = x.numel()
     y = torch.empty_like(x)
     mask = torch.empty(n // group, device=x.device, dtype=torch.float32)
+    if DROPOUT_BASE is not None:
+        N.check(N.load().icap_dropout_dev_f32(x.data_ptr(), float(p), int(seed) & (2 ** 64 - 1), int(offset), DROPOUT_BASE.data_ptr(), n,
+                                              group, y.data_ptr(), mask.data_ptr(), _stream()), "dropout_dev")
+        return y, mask
     N.check(N.load().icap_dropout_f32(x.data_ptr(), float(p), int(seed) & (2 ** 64 - 1), int(offset), n, group, y.data_ptr(),
                                       mask.data_ptr(), _stream()), "dropout")
     return y, mask

@@ -198,6 +198,23 @@ class AdamW:
                                        self.v.data_ptr() + 4 * lo, hi - lo, self.lr, self.betas[0], self.betas[1], self.eps,
                                        self.weight_decay, step, float(f.grad_scale), _stream()), "adamw")
 
+    def record_step(self, step_dev: torch.Tensor) -> None:
+        """The launches of ``step`` with the step count read from `step_dev` (int32 [1] on the device, holding the count
+        of the step being taken) instead of passed by value - what a step recorded in a HIP graph needs.  Changes no
+        host state; ``advance_recorded`` does that once per replay."""
+        f = self.flat
+        lib = N.load()
+        nxt = [s + 1 if t else s for s, t in zip(self.param_steps, f.touched)]
+        for lo, hi, step in f.touched_runs(nxt):
+            N.check(lib.icap_adamw_dev_f32(f.flat_p.data_ptr() + 4 * lo, f.flat_g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
+                                           self.v.data_ptr() + 4 * lo, hi - lo, self.lr, self.betas[0], self.betas[1], self.eps,
+                                           self.weight_decay, step_dev.data_ptr(), step - (self.steps + 1), float(f.grad_scale),
+                                           _stream()), "adamw_dev")
+
+    def advance_recorded(self, touched) -> None:
+        self.steps += 1
+        self.param_steps = [s + 1 if t else s for s, t in zip(self.param_steps, touched)]
+
     def state_dict(self):
         return {"step": self.steps, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr, "betas": self.betas,
                 "eps": self.eps, "weight_decay": self.weight_decay}
@@ -343,18 +360,22 @@ class Trainer:
     """
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, group=None, bucket_mb=16.0,
-                 loss="compute_loss", overlap=False, dtype="f32"):
+                 loss="compute_loss", overlap=False, dtype="f32", graph=False):
         import torch.distributed as dist
         if dtype not in ("f32", "bf16"):
             raise ValueError(f"Trainer: dtype must be 'f32' or 'bf16', not {dtype!r}")
         self.model = model
+        self.graph = bool(graph)
+        self._graph, self._eager_steps = None, 0
         self.dtype = dtype                   # "bf16": bf16 products in forward and input gradients, fp32 master weights
                                              # / accumulation / weight gradients / optimizer (ops.train_step)
         self.opt = AdamW(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.reducer = GradientReducer(self.opt, group=group, bucket_mb=bucket_mb, overlap=overlap) if dist.is_available() and dist.is_initialized() else None
         self.loss_kind = loss
+        if self.graph and self.reducer is not None:
+            raise ValueError("Trainer(graph=True): single-process training only (the gradient exchange is not recorded)")
 
-    def step(self, images, captions, padding_idx):
+    def _forward_backward(self, images, captions, padding_idx):
         self.model.train()
         self.opt.zero_grad()
         if self.reducer is not None:
@@ -368,5 +389,60 @@ class Trainer:
             loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
-        self.opt.step()
         return loss.detach()
+
+    def step(self, images, captions, padding_idx):
+        if self.graph:
+            return self._graph_step(images, captions, padding_idx)
+        loss = self._forward_backward(images, captions, padding_idx)
+        self.opt.step()
+        return loss
+
+    # ---- the step as one HIP graph (graph=True): for small per-GPU batches, where ~2000 launches per step make the
+    # host the bottleneck.  Two eager steps first (allocator pools, the set of parameters that receive gradients), then
+    # the third call records zero_grad + forward + loss + backward + AdamW into a graph on static input buffers; from
+    # then on a step is two copies into those buffers and one graph launch.  What changes from step to step lives in
+    # device memory and is advanced inside the graph: the dropout generator's offset base and AdamW's step count.
+    def _graph_step(self, images, captions, padding_idx):
+        if self._graph is None:
+            if self._eager_steps < 2:
+                self._eager_steps += 1
+                loss = self._forward_backward(images, captions, padding_idx)
+                self.opt.step()
+                return loss
+            self._record(images, captions, padding_idx)
+        if images.shape != self._images.shape or captions.shape != self._caps.shape or padding_idx != self._pad:
+            raise ValueError("Trainer(graph=True): every step must have the shapes (and padding index) of the recorded one")
+        from ._bah_train import DropoutState
+        self._images.copy_(images)
+        self._caps.copy_(captions)
+        self._graph.replay()
+        DropoutState.offset += self._draws_per_step
+        self.opt.advance_recorded(self._touched)
+        return self._loss.clone()
+
+    def _record(self, images, captions, padding_idx):
+        from . import train_ops as T
+        from ._bah_train import DropoutState
+        dev = images.device
+        self._images, self._caps, self._pad = images.clone(), captions.clone(), padding_idx
+        self._offset_base = torch.zeros(1, device=dev, dtype=torch.int64)
+        self._step_dev = torch.full((1,), self.opt.steps, device=dev, dtype=torch.int32)
+        o0 = DropoutState.offset
+        tune, ops.AUTOTUNE = ops.AUTOTUNE, False          # tuning synchronises; a recording must not
+        T.DROPOUT_BASE = self._offset_base
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                self._loss = self._forward_backward(self._images, self._caps, padding_idx)
+                self._step_dev.add_(1)
+                self.opt.record_step(self._step_dev)
+                self._draws_per_step = DropoutState.offset - o0
+                self._offset_base.add_(self._draws_per_step)
+        finally:
+            T.DROPOUT_BASE = None
+            ops.AUTOTUNE = tune
+        DropoutState.offset = o0                          # recording ran nothing: the first replay makes these draws
+        self._touched = list(self.opt.flat.touched)
+        self._graph = graph

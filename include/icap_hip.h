@@ -342,6 +342,12 @@ int icap_ce_loss_bwd_f32(const float* logits, int ld, int group_rows, int group_
 int icap_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* icap_adamw_f32 with the step count t = *step_dev + step_bias read from device memory by the kernel: the form a
+ * training step recorded in a HIP graph needs (launch arguments are frozen in a graph; the caller advances *step_dev
+ * inside the graph).  Same update, same reference lines. */
+int icap_adamw_dev_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, const int* step_dev, int step_bias, float grad_scale, void* stream);
+
 /* ------------------------------------------------------------------ training step: backward GEMMs
  * C[M][N] (+)= op(A) . B, B stored [K][N]; op(A) = A stored [M][K] (a_kmajor = 0: dX = dY . W, the input
  * gradient of every nn.Linear / 1x1 convolution) or A stored [K][M] (a_kmajor = 1: dW = dY^T . X, the weight
@@ -393,6 +399,12 @@ int icap_axpby_f32(const float* x, float alpha, float beta, float* y, long long 
  * by (seed, offset + index / group); mask [n / group] is kept for the backward pass. */
 int icap_dropout_f32(const float* x, float p, unsigned long long seed, unsigned long long offset, long long n,
                      long long group, float* y, float* mask, void* stream);
+/* icap_dropout_f32 with the generator offset = offset + *offset_base, the base read from device memory by the kernel
+ * (for a training step recorded in a HIP graph: the caller advances the base inside the graph, so every replay draws
+ * new masks).  Same reference lines. */
+int icap_dropout_dev_f32(const float* x, float p, unsigned long long seed, unsigned long long offset,
+                         const unsigned long long* offset_base, long long n, long long group, float* y, float* mask,
+                         void* stream);
 /* y = x * mask[i / group] (+ add): re-applies a stored mask (backward of dropout; forward with a given mask). */
 int icap_mul_mask_f32(const float* x, const float* mask, long long group, const float* add, long long n, float* y,
                       void* stream);

@@ -1,0 +1,74 @@
+"""Trainer(graph=True): the training step recorded once into a HIP graph and replayed must do what the eager step does -
+same losses, same parameters after several steps with changing inputs, new dropout masks on every replay, AdamW's bias
+correction advancing."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+D = "cuda:0"
+
+
+def _run(graph, steps, dropout=0.3):
+    from image_captioning_amd import transformer_word_level_bahdnau as my_bah
+    from image_captioning_amd._bah_train import DropoutState
+    from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images
+    from image_captioning_amd.training import Trainer
+    V, B, T = 300, 4, 6
+    batches = [(synthetic_images(B, seed=10 + i).to(D), synthetic_captions(B, T, V, 2, 3, 0, seed=20 + i).to(D)) for i in range(3)]
+    model = my_bah.build_model(V, dropout=dropout)
+    model.load_state_dict(seeded_state_dict(model, seed=5))
+    model.to(D)
+    DropoutState.manual_seed(123)
+    trainer = Trainer(model, lr=1e-3, weight_decay=1e-2, graph=graph)
+    losses = []
+    for i in range(steps):
+        im, cp = batches[i % 3]
+        losses.append(trainer.step(im, cp, 0).item())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return losses, sd, trainer, DropoutState.offset
+
+
+def test_recorded_step_matches_eager_step():
+    steps = 7                                        # 2 eager warm-up steps, the recording, 5 replays
+    l_e, sd_e, tr_e, off_e = _run(False, steps)
+    l_g, sd_g, tr_g, off_g = _run(True, steps)
+    assert tr_g._graph is not None
+    assert off_e == off_g                            # the host's view of the dropout generator stays in step
+    assert tr_e.opt.steps == tr_g.opt.steps == steps and tr_e.opt.param_steps == tr_g.opt.param_steps
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 1e-4 * abs(a), (l_e, l_g)
+    assert len(set(round(v, 6) for v in l_g)) == steps          # every step saw its own inputs / masks / weights
+    bad = []
+    for k, want in sd_e.items():
+        got = sd_g[k]
+        if not want.is_floating_point():
+            assert torch.equal(got, want), k                     # num_batches_tracked
+            continue
+        err = (got - want).abs().max().item()
+        if err > 1e-4 * want.abs().max().item() + 1e-6:
+            bad.append((k, err, want.abs().max().item()))
+    assert not bad, bad[:10]
+
+
+def test_replays_draw_new_dropout_masks():
+    """Same inputs every step, learning rate 0: only the dropout masks can change the loss from replay to replay."""
+    from image_captioning_amd import transformer_word_level_bahdnau as my_bah
+    from image_captioning_amd._bah_train import DropoutState
+    from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images
+    from image_captioning_amd.training import Trainer
+    V, B, T = 300, 4, 6
+    im, cp = synthetic_images(B, seed=1).to(D), synthetic_captions(B, T, V, 2, 3, 0, seed=2).to(D)
+    model = my_bah.build_model(V, dropout=0.5)
+    model.load_state_dict(seeded_state_dict(model, seed=5))
+    model.to(D)
+    DropoutState.manual_seed(7)
+    trainer = Trainer(model, lr=0.0, weight_decay=0.0, graph=True)
+    losses = [trainer.step(im, cp, 0).item() for _ in range(6)]
+    assert len(set(losses[2:])) == 4, losses
+
+
+def test_graph_rejects_other_shapes():
+    l, sd, trainer, _ = _run(True, 3)
+    from image_captioning_amd.synthetic import synthetic_captions, synthetic_images
+    with pytest.raises(ValueError):
+        trainer.step(synthetic_images(2, seed=1).to(D), synthetic_captions(2, 6, 300, 2, 3, 0, seed=2).to(D), 0)

@@ -8,7 +8,7 @@ resize + normalise on the GPU -> Trainer.step (train-mode forward, compute_loss,
 process group is up, AdamW).  Then the 1 346 test images, sharded by rank, are resized and captioned greedily
 (20 tokens, batches of --caption-batch).  JPEG decoding (host, PIL) is not part of it.
 
-    python tools/epoch_bench.py [--batch 12] [--dtype f32|bf16] [--images 13455]
+    python tools/epoch_bench.py [--batch 12] [--dtype f32|bf16] [--graph] [--images 13455]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/epoch_bench.py
 
 Prints one JSON object (rank 0).
@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=12, help="loader batch per GPU (the reference's: 12)")
     ap.add_argument("--caption-batch", type=int, default=256)
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32")
+    ap.add_argument("--graph", action="store_true", help="record the training step into a HIP graph (single process only)")
     ap.add_argument("--max-steps", type=int, default=0, help="stop the epoch early (0 = whole epoch)")
     args = ap.parse_args()
 
@@ -65,7 +66,7 @@ def main():
     model.load_state_dict(seeded_state_dict(model, seed=52))
     model = model.to(dev)
     DropoutState.manual_seed(1000 + rank)
-    trainer = Trainer(model, lr=1e-4, weight_decay=1e-5, dtype=args.dtype)
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-5, dtype=args.dtype, graph=args.graph)
 
     def train_step(i):
         o = (i % 4) * B
@@ -125,7 +126,7 @@ def main():
         print(json.dumps({
             "workload": "word-level Bahdanau captioner: one training epoch + greedy captioning of the test split, synthetic pixels and titles "
                         "of the reference data set's shape (BASELINE configs[4])",
-            "n_gpus": world, "dtype": args.dtype, "images": args.images, "train_images": n_train, "test_images": n_test,
+            "n_gpus": world, "dtype": args.dtype, "hip_graph": bool(args.graph), "images": args.images, "train_images": n_train, "test_images": n_test,
             "loader_batch_per_gpu": B, "steps": steps, "epoch_train_s": t_train, "train_imgs_per_s": steps * B * world / t_train,
             "ms_per_step": t_train / steps * 1e3, "loss_last_step": float(loss), "caption_s": t_cap,
             "captions_per_s": n_test / t_cap, "caption_batch": CB, "caption_tokens": TOKENS, "ids_shape": list(ids.shape),

@@ -49,7 +49,7 @@ def parse():
                     help="compute dtype of the GEMMs: f32 (default, the reference's), or bf16 products with fp32 accumulation and "
                          "fp32 tensors in memory (training mode: forward GEMMs and input gradients; fp32 weight gradients)")
     ap.add_argument("--graph", action="store_true",
-                    help="training mode: record the step into a HIP graph (Trainer(graph=True); single GPU, pays at small batches)")
+                    help="training mode: record the step into HIP graphs (Trainer(graph=True); pays at small batches)")
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the secondary bf16-mode measurement")
     ap.add_argument("--no-train-mode", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--train-batch", type=int, default=256, help="images per step per GPU of the secondary training measurement")
@@ -278,7 +278,7 @@ def main():
     pool = synthetic_images(min(B, 32), seed=1234 + rank)
     images = pool.repeat((B + pool.shape[0] - 1) // pool.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
     if train:
-        model, step = build_train_step(torch, dev, rank, B, args.dtype, args.graph and world == 1)
+        model, step = build_train_step(torch, dev, rank, B, args.dtype, args.graph)
     else:
         model = twl.build_model(VOCAB)
         model.load_state_dict(seeded_state_dict(model, seed=52))
@@ -317,7 +317,7 @@ def main():
 
     # --graph: tuning and the dominant-kernel events come from eager steps (a replayed graph makes no traced launches; it
     # runs the same kernels), then the step is recorded and the timed region replays it
-    graph_mode = train and args.graph and world == 1
+    graph_mode = train and args.graph
     if graph_mode:
         step.trainer.graph = False
     note(rank, f"process group and model ready ({'train' if train else 'caption'} mode, batch {B}, world {world})")
@@ -398,7 +398,7 @@ def main():
         roof["avg_launch_ms"] = dom_ms
         if train:
             workload = TRAIN_WORKLOAD
-            par = train_parallelism(model, world) + (", step replayed from a HIP graph" if args.graph and world == 1 else "")
+            par = train_parallelism(model, world) + (", step replayed from HIP graphs" if args.graph else "")
         else:
             workload = ("transformer_word_level: EfficientNet-B0 encoder + word-level transformer decoder, "
                         "batched greedy captioning (BASELINE configs[1])")

@@ -145,6 +145,10 @@ def load():
         raise IcapError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C image_captioning_amd/csrc`; there is no CPU fallback")
+    # torch first: its own copy of the HIP runtime must be the one in the process before this library asks the loader
+    # for libamdhip64 - loaded the other way round, the process ends up with two runtimes and the second one to
+    # initialise finds no device
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

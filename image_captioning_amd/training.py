@@ -366,19 +366,20 @@ class Trainer:
             raise ValueError(f"Trainer: dtype must be 'f32' or 'bf16', not {dtype!r}")
         self.model = model
         self.graph = bool(graph)
-        self._graph, self._eager_steps = None, 0
+        self._graph, self._graph_opt, self._eager_steps = None, None, 0
         self.dtype = dtype                   # "bf16": bf16 products in forward and input gradients, fp32 master weights
                                              # / accumulation / weight gradients / optimizer (ops.train_step)
         self.opt = AdamW(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.reducer = GradientReducer(self.opt, group=group, bucket_mb=bucket_mb, overlap=overlap) if dist.is_available() and dist.is_initialized() else None
         self.loss_kind = loss
-        if self.graph and self.reducer is not None:
-            raise ValueError("Trainer(graph=True): single-process training only (the gradient exchange is not recorded)")
+        if self.graph and self.reducer is not None and self.reducer.overlap:
+            raise ValueError("Trainer(graph=True): the gradient exchange runs between the two recorded graphs; overlap=True is not supported")
 
-    def _forward_backward(self, images, captions, padding_idx):
+    def _forward_backward(self, images, captions, padding_idx, exchange=True):
+        exchange = exchange and self.reducer is not None
         self.model.train()
         self.opt.zero_grad()
-        if self.reducer is not None:
+        if exchange:
             self.reducer.prepare()
         with ops.train_step(self.dtype):      # per-step weight copies live until backward is done
             predictions = self.model(images, captions)
@@ -387,7 +388,7 @@ class Trainer:
             else:
                 loss = CrossEntropyLoss(ignore_index=padding_idx)(predictions.reshape(-1, predictions.size(-1)), captions.reshape(-1))
             loss.backward()
-        if self.reducer is not None:
+        if exchange:
             self.reducer.finish()
         return loss.detach()
 
@@ -403,6 +404,8 @@ class Trainer:
     # the third call records zero_grad + forward + loss + backward + AdamW into a graph on static input buffers; from
     # then on a step is two copies into those buffers and one graph launch.  What changes from step to step lives in
     # device memory and is advanced inside the graph: the dropout generator's offset base and AdamW's step count.
+    # Under data parallelism the step is two graphs - everything up to the gradients, and the optimizer - with the
+    # gradient exchange launched between them in the ordinary way, so no collective is ever recorded.
     def _graph_step(self, images, captions, padding_idx):
         if self._graph is None:
             if self._eager_steps < 2:
@@ -417,6 +420,10 @@ class Trainer:
         self._images.copy_(images)
         self._caps.copy_(captions)
         self._graph.replay()
+        if self._graph_opt is not None:
+            self.reducer.prepare()
+            self.reducer.finish()
+            self._graph_opt.replay()
         DropoutState.offset += self._draws_per_step
         self.opt.advance_recorded(self._touched)
         return self._loss.clone()
@@ -433,16 +440,25 @@ class Trainer:
         T.DROPOUT_BASE = self._offset_base
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        graph_opt = torch.cuda.CUDAGraph() if self.reducer is not None else None
+
+        def record_optimizer():
+            self._step_dev.add_(1)
+            self.opt.record_step(self._step_dev)
+            self._draws_per_step = DropoutState.offset - o0
+            self._offset_base.add_(self._draws_per_step)
+
         try:
             with torch.cuda.graph(graph):
-                self._loss = self._forward_backward(self._images, self._caps, padding_idx)
-                self._step_dev.add_(1)
-                self.opt.record_step(self._step_dev)
-                self._draws_per_step = DropoutState.offset - o0
-                self._offset_base.add_(self._draws_per_step)
+                self._loss = self._forward_backward(self._images, self._caps, padding_idx, exchange=False)
+                if graph_opt is None:
+                    record_optimizer()
+            if graph_opt is not None:
+                with torch.cuda.graph(graph_opt):
+                    record_optimizer()
         finally:
             T.DROPOUT_BASE = None
             ops.AUTOTUNE = tune
         DropoutState.offset = o0                          # recording ran nothing: the first replay makes these draws
         self._touched = list(self.opt.flat.touched)
-        self._graph = graph
+        self._graph, self._graph_opt = graph, graph_opt

@@ -72,3 +72,21 @@ def test_graph_rejects_other_shapes():
     from image_captioning_amd.synthetic import synthetic_captions, synthetic_images
     with pytest.raises(ValueError):
         trainer.step(synthetic_images(2, seed=1).to(D), synthetic_captions(2, 6, 300, 2, 3, 0, seed=2).to(D), 0)
+
+
+def test_two_graph_form_with_a_process_group():
+    """With a process group up the step is recorded as two graphs with the gradient exchange between them; a single-rank
+    group exercises that structure (the exchange itself is covered by the gloo tests on CPU)."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1)
+    try:
+        l_g, sd_g, tr_g, _ = _run(True, 6)
+        assert tr_g.reducer is not None and tr_g._graph_opt is not None
+    finally:
+        dist.destroy_process_group()
+    l_e, sd_e, _, _ = _run(False, 6)
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 1e-4 * abs(a), (l_e, l_g)
+    for k, want in sd_e.items():
+        if want.is_floating_point():
+            assert (sd_g[k] - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 1e-6, k

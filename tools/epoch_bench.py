@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=12, help="loader batch per GPU (the reference's: 12)")
     ap.add_argument("--caption-batch", type=int, default=256)
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32")
-    ap.add_argument("--graph", action="store_true", help="record the training step into a HIP graph (single process only)")
+    ap.add_argument("--graph", action="store_true", help="record the training step into HIP graphs (Trainer(graph=True))")
     ap.add_argument("--max-steps", type=int, default=0, help="stop the epoch early (0 = whole epoch)")
     args = ap.parse_args()
 

@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
 // TX threads span 4*TX adjacent columns with one float4 each and 256/TX threads share the chunk's rows, so a
 // wave reads whole contiguous rows whatever the channel count (16 ... 1152 in EfficientNet-B0); the row lanes
 // meet in LDS in a fixed order.
-template <int MODE, int TX>
+// ACT >= 0 fixes the activation of the BatchNorm-gradient mode at compile time (a run-time switch per element costs a
+// scalar branch tree around the transcendental instructions); ACT < 0 reads the `act` argument.
+template <int MODE, int TX, int ACT = -1>
 __global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __restrict__ a, int lda, const float* __restrict__ x,
                                                               int ldx, const float* __restrict__ v1, const float* __restrict__ v2,
                                                               const float* __restrict__ v3, const float* __restrict__ v4,
@@ -107,6 +109,29 @@ __global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __res
             sc = *reinterpret_cast<const float4*>(v3 + c);
             bi = *reinterpret_cast<const float4*>(v4 + c);
         }
+        if (MODE == COL_BN_BWD) {
+            // two rows per iteration, all four loads issued before the arithmetic; the second row is read from a clamped
+            // address and weighted 0 when it lies beyond the chunk
+            const int actc = ACT >= 0 ? ACT : act;
+            for (int r = r_lo + ty; r < r_hi; r += 2 * TY) {
+                const int rb = min(r + TY, r_hi - 1);
+                const float wb = r + TY < r_hi ? 1.f : 0.f;
+                const float4 av = *reinterpret_cast<const float4*>(a + (size_t)r * lda + c);
+                const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+                const float4 aw = *reinterpret_cast<const float4*>(a + (size_t)rb * lda + c);
+                const float4 xw = *reinterpret_cast<const float4*>(x + (size_t)rb * ldx + c);
+                const float g0 = av.x * act_grad(fmaf(xv.x, sc.x, bi.x), actc), g1 = av.y * act_grad(fmaf(xv.y, sc.y, bi.y), actc);
+                const float g2 = av.z * act_grad(fmaf(xv.z, sc.z, bi.z), actc), g3 = av.w * act_grad(fmaf(xv.w, sc.w, bi.w), actc);
+                s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
+                s2.x += g0 * ((xv.x - m.x) * rs.x); s2.y += g1 * ((xv.y - m.y) * rs.y);
+                s2.z += g2 * ((xv.z - m.z) * rs.z); s2.w += g3 * ((xv.w - m.w) * rs.w);
+                const float h0 = wb * aw.x * act_grad(fmaf(xw.x, sc.x, bi.x), actc), h1 = wb * aw.y * act_grad(fmaf(xw.y, sc.y, bi.y), actc);
+                const float h2 = wb * aw.z * act_grad(fmaf(xw.z, sc.z, bi.z), actc), h3 = wb * aw.w * act_grad(fmaf(xw.w, sc.w, bi.w), actc);
+                s1.x += h0; s1.y += h1; s1.z += h2; s1.w += h3;
+                s2.x += h0 * ((xw.x - m.x) * rs.x); s2.y += h1 * ((xw.y - m.y) * rs.y);
+                s2.z += h2 * ((xw.z - m.z) * rs.z); s2.w += h3 * ((xw.w - m.w) * rs.w);
+            }
+        } else
         for (int r = r_lo + ty; r < r_hi; r += TY) {
             const float4 av = *reinterpret_cast<const float4*>(a + (size_t)r * lda + c);
             if (MODE == COL_SUM) {
@@ -200,15 +225,15 @@ long long col_reduce_ws_floats(int M, int C) {
     return 2LL * (chunks_vec > chunks_scalar ? chunks_vec : chunks_scalar) * C;
 }
 
-template <int MODE>
+template <int MODE, int ACT = -1>
 static void col_launch_vec(int tx, dim3 grid, hipStream_t st, const float* a, int lda, const float* x, int ldx, const float* v1,
                            const float* v2, const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C,
                            int rpc, float* ws) {
     switch (tx) {
-        case 8: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 8>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
-        case 16: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 16>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
-        case 32: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 32>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
-        default: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 64>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+        case 8: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 8, ACT>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+        case 16: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 16, ACT>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+        case 32: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 32, ACT>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+        default: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 64, ACT>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
     }
 }
 
@@ -232,7 +257,11 @@ int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, c
         switch (mode) {
             case COL_SUM: col_launch_vec<COL_SUM>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
             case COL_SQDEV: col_launch_vec<COL_SQDEV>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
-            case COL_BN_BWD: col_launch_vec<COL_BN_BWD>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+            case COL_BN_BWD:
+                if (act == ACT_SWISH) col_launch_vec<COL_BN_BWD, ACT_SWISH>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws);
+                else if (act == ACT_NONE) col_launch_vec<COL_BN_BWD, ACT_NONE>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws);
+                else col_launch_vec<COL_BN_BWD>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws);
+                break;
             case COL_MOMENTS: col_launch_vec<COL_MOMENTS>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
             default: col_launch_vec<COL_LN_BWD>(tx, grid, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
         }
@@ -325,6 +354,7 @@ __global__ __launch_bounds__(256) void scale_bias_act_kernel(const float* __rest
 }
 
 // 16 bytes per lane when every row start and the channel count allow it
+template <int ACT>      // >= 0: the activation fixed at compile time; < 0: the `act` argument decides per element
 __global__ __launch_bounds__(256) void scale_bias_act_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ s,
                                                                  const float* __restrict__ b, const float* __restrict__ res,
                                                                  int ldr, int act, int M, int C4, float* __restrict__ y, int ldy) {
@@ -334,8 +364,9 @@ __global__ __launch_bounds__(256) void scale_bias_act_vec_kernel(const float* __
         const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
         const float4 sv = s ? *reinterpret_cast<const float4*>(s + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 bv = b ? *reinterpret_cast<const float4*>(b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 v = make_float4(act_apply(fmaf(xv.x, sv.x, bv.x), act), act_apply(fmaf(xv.y, sv.y, bv.y), act),
-                               act_apply(fmaf(xv.z, sv.z, bv.z), act), act_apply(fmaf(xv.w, sv.w, bv.w), act));
+        const int a_ = ACT >= 0 ? ACT : act;
+        float4 v = make_float4(act_apply(fmaf(xv.x, sv.x, bv.x), a_), act_apply(fmaf(xv.y, sv.y, bv.y), a_),
+                               act_apply(fmaf(xv.z, sv.z, bv.z), a_), act_apply(fmaf(xv.w, sv.w, bv.w), a_));
         if (res) {
             const float4 rv = *reinterpret_cast<const float4*>(res + (size_t)r * ldr + c);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
@@ -357,7 +388,12 @@ int scale_bias_act_f32(const float* x, int ldx, const float* s, const float* b, 
     if (vec4_ok(M, C, {ldx, ldy, res ? ldr : 0}, {x, y, s, b, res})) {
         long long vb = ((long long)M * (C / 4) + 255) / 256;
         if (vb > 16384) vb = 16384;
-        hipLaunchKernelGGL(scale_bias_act_vec_kernel, dim3((unsigned)vb), dim3(256), 0, st, x, ldx, s, b, res, ldr, act, M, C / 4, y, ldy);
+        if (act == ACT_SWISH)
+            hipLaunchKernelGGL(scale_bias_act_vec_kernel<ACT_SWISH>, dim3((unsigned)vb), dim3(256), 0, st, x, ldx, s, b, res, ldr, act, M, C / 4, y, ldy);
+        else if (act == ACT_NONE)
+            hipLaunchKernelGGL(scale_bias_act_vec_kernel<ACT_NONE>, dim3((unsigned)vb), dim3(256), 0, st, x, ldx, s, b, res, ldr, act, M, C / 4, y, ldy);
+        else
+            hipLaunchKernelGGL(scale_bias_act_vec_kernel<-1>, dim3((unsigned)vb), dim3(256), 0, st, x, ldx, s, b, res, ldr, act, M, C / 4, y, ldy);
         return launch_status("scale_bias_act");
     }
     long long blocks = ((long long)M * C + 255) / 256;
@@ -386,6 +422,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
     }
 }
 
+template <int ACT>      // >= 0: the activation fixed at compile time; < 0: the `act` argument decides per element
 __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ s, const float* __restrict__ b,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -405,7 +442,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const float* __rest
         const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
         float o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = dv[k] * act_grad(fmaf(xv[k], sv[k], bv[k]), act);
+        for (int k = 0; k < 4; ++k) o[k] = dv[k] * act_grad(fmaf(xv[k], sv[k], bv[k]), ACT >= 0 ? ACT : act);
         if (mean) {
             const float4 m4 = *reinterpret_cast<const float4*>(mean + c), r4 = *reinterpret_cast<const float4*>(rstd + c);
             const float4 g4 = *reinterpret_cast<const float4*>(dgamma + c), e4 = *reinterpret_cast<const float4*>(dbeta + c);
@@ -430,8 +467,15 @@ int bn_act_bwd_f32(const float* dy, int ldd, const float* x, int ldx, const floa
     if (vec4_ok(M, C, {ldd, ldx, ldo}, {dy, x, dx, s, b, mean, rstd, dgamma, dbeta})) {
         long long vb = ((long long)M * (C / 4) + 255) / 256;
         if (vb > 16384) vb = 16384;
-        hipLaunchKernelGGL(bn_act_bwd_vec_kernel, dim3((unsigned)vb), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma, dbeta, act, M,
-                           C / 4, dx, ldo);
+        if (act == ACT_SWISH)
+            hipLaunchKernelGGL(bn_act_bwd_vec_kernel<ACT_SWISH>, dim3((unsigned)vb), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma,
+                               dbeta, act, M, C / 4, dx, ldo);
+        else if (act == ACT_NONE)
+            hipLaunchKernelGGL(bn_act_bwd_vec_kernel<ACT_NONE>, dim3((unsigned)vb), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma,
+                               dbeta, act, M, C / 4, dx, ldo);
+        else
+            hipLaunchKernelGGL(bn_act_bwd_vec_kernel<-1>, dim3((unsigned)vb), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma, dbeta,
+                               act, M, C / 4, dx, ldo);
         return launch_status("bn_act_bwd");
     }
     long long blocks = ((long long)M * C + 255) / 256;

@@ -90,3 +90,39 @@ def test_two_graph_form_with_a_process_group():
     for k, want in sd_e.items():
         if want.is_floating_point():
             assert (sd_g[k] - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 1e-6, k
+
+
+@pytest.mark.parametrize("kind", ["word_transformer", "seq2seq_lstm"])
+def test_recorded_step_for_the_other_models(kind):
+    """The word-level transformer (compute_loss) and the ResNet-18 + LSTM model (CrossEntropyLoss, frozen trunk with
+    train-mode BatchNorm): recorded steps against eager steps."""
+    from image_captioning_amd._bah_train import DropoutState
+    from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images
+    from image_captioning_amd.training import Trainer
+    V, B, T = 300, 4, 6
+    batches = [(synthetic_images(B, seed=30 + i).to(D), synthetic_captions(B, T, V, 2, 3, 0, seed=40 + i).to(D)) for i in range(2)]
+
+    def run(graph):
+        if kind == "word_transformer":
+            from image_captioning_amd import transformer_word_level as twl
+            model, loss = twl.build_model(V), "compute_loss"
+        else:
+            from image_captioning_amd import seq2seqbasic as s2s
+            model, loss = s2s.ImageCaptioningModel(256, 512, V, "resnet18", "lstm", 2), "cross_entropy"
+        model.load_state_dict(seeded_state_dict(model, seed=6))
+        model.to(D)
+        DropoutState.manual_seed(5)
+        trainer = Trainer(model, lr=1e-3, weight_decay=1e-2, loss=loss, graph=graph)
+        losses = [trainer.step(*batches[i % 2], 0).item() for i in range(6)]
+        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, trainer
+
+    l_e, sd_e, _ = run(False)
+    l_g, sd_g, tr = run(True)
+    assert tr._graph is not None
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 1e-4 * abs(a), (l_e, l_g)
+    for k, want in sd_e.items():
+        if want.is_floating_point():
+            assert (sd_g[k] - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 1e-6, k
+        else:
+            assert torch.equal(sd_g[k], want), k

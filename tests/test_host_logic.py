@@ -105,3 +105,39 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         parallel.shard_range(5, 2, 2)
+
+
+def test_train_step_context_and_step_cache():
+    """ops.train_step: per-step state of the training GEMMs (host logic only - no library call is made here)."""
+    import pytest
+    import torch
+    from image_captioning_amd import ops
+    calls = []
+    w = torch.zeros(4, 8)
+
+    def make():
+        calls.append(1)
+        return object()
+
+    assert ops.step_cached("k", w, make) is not ops.step_cached("k", w, make)      # outside a step nothing is kept
+    assert len(calls) == 2
+    with ops.train_step("bf16"):
+        assert ops.TRAIN_DTYPE == "bf16"
+        a = ops.step_cached("k", w, make)
+        assert ops.step_cached("k", w, make) is a                                  # once per (kind, tensor) within a step
+        assert ops.step_cached("other", w, make) is not a
+        assert ops.step_cached("k", w[:, :4], make) is not a                       # another view: another entry
+        with ops.train_step("f32"):                                                # nesting restores the outer state
+            assert ops.TRAIN_DTYPE == "f32" and ops.step_cached("k", w, make) is not a
+        assert ops.TRAIN_DTYPE == "bf16" and ops.step_cached("k", w, make) is a
+    assert ops.TRAIN_DTYPE == "f32" and ops._step_cache is None
+    with pytest.raises(ops.IcapError):
+        ops.train_step("fp8")
+
+
+def test_trainer_rejects_unknown_dtype():
+    import pytest
+    import torch
+    from image_captioning_amd.training import Trainer
+    with pytest.raises(ValueError):
+        Trainer(torch.nn.Linear(2, 2), dtype="fp8")

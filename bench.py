@@ -210,6 +210,31 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
         elapsed = float(t.item())
     res["bf16"] = {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "dtype": TRAIN_DTYPES["bf16"],
                    "loss_last_step": float(loss), "tolerance": TRAIN_BF16_TOLERANCE}
+    # single process only: the step at the reference's loader batch (12), replayed from a HIP graph (Trainer(graph=True))
+    if world == 1:
+        try:
+            del model, step
+            torch.cuda.empty_cache()
+            gb = 12
+            _, gstep = build_train_step(torch, dev, rank, gb, "f32", graph=True)
+            ops.set_autotune(True)
+            gstep()
+            torch.cuda.synchronize()
+            ops.set_autotune(False)
+            for _ in range(4):              # second eager step, the recording with its first replay, two more replays
+                gstep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5 * steps):
+                loss = gstep()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            res["graph_b12"] = {"value": gb * 5 * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / (5 * steps) * 1e3, "steps": 5 * steps,
+                                "images_per_step_per_gpu": gb, "dtype": "f32", "loss_last_step": float(loss),
+                                "note": "the reference's loader batch; zero_grad + forward + loss + backward + AdamW replayed from one HIP graph"}
+            note(rank, f"train secondary, graph-replayed step at batch {gb}: {5 * steps} steps in {elapsed:.2f} s")
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            res["graph_b12"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return res
 
 

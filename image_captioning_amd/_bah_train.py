@@ -172,14 +172,9 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         bn_saved = []
         for t in range(Tn):
             x_t = pre[t * B:(t + 1) * B]
-            mean = T.col_reduce(T.COL_SUM, x_t, scale=1.0 / B)[0]
-            sqdev = T.col_reduce(T.COL_SQDEV, x_t, v1=mean)[0]
-            rstd = torch.empty(V, device=dev); s = torch.empty(V, device=dev); b = torch.empty(V, device=dev)
-            T.N.check(T.N.load().icap_bn_finalize_f32(mean.data_ptr(), sqdev.data_ptr(), bn_g.data_ptr(), bn_b.data_ptr(), float(bn.eps),
-                                                      float(mom), B, V, rstd.data_ptr(), s.data_ptr(), b.data_ptr(),
-                                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), ops._stream()), "bn_finalize")
-            T.scale_bias_act(x_t, s, b, out=out[:, t, :])
-            bn_saved.append((mean, rstd, s, b))
+            # one pass over the step's rows (moments about the first row), the running statistics updated in step order
+            _, saved = T.batchnorm_train(x_t, bn_g, bn_b, bn.running_mean, bn.running_var, bn.eps, mom, out=out[:, t, :])
+            bn_saved.append(saved)
         bn.num_batches_tracked += Tn
         ctx.saved = (feats, idx, emb_all, w_ih_e, w_ih_c, u, a_w, Hprev, Cs, Ws, Al, Ctx, G, hd, m_out, pre, bn_saved)
         ctx.params = (W_w, U_w, w_ih, w_hh, fc_w, emb_w)

@@ -110,7 +110,7 @@ def col_sum(a, out=None, accumulate=False, scale=1.0):
     return col_reduce(COL_SUM, a, out1=out, accumulate=accumulate, scale=scale)[0]
 
 
-def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NONE, res=None):
+def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NONE, res=None, out=None):
     """BatchNorm over the rows of x [M, C] with batch statistics (+ activation, + residual); updates the running
     statistics in place.  Returns (y, saved) with saved = (mean, rstd, s, b) for the backward pass."""
     _ckr(x, "x")
@@ -124,7 +124,7 @@ def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NO
     N.check(lib.icap_bn_finalize_moments_f32(shift.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(gamma), _p(beta), float(eps),
                                              float(momentum), M, C, mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), b.data_ptr(),
                                              _p(run_mean), _p(run_var), _stream()), "bn_finalize_moments")
-    y = scale_bias_act(x, s, b, act=act, res=res)
+    y = scale_bias_act(x, s, b, act=act, res=res, out=out)
     return y, (mean, rstd, s, b)
 
 

@@ -142,24 +142,28 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         u = _lin(feats, U_w, U_b)
         a_w = A_w.detach().view(-1).contiguous()
         a_b = 0.0   # the scoring bias shifts every score of a softmax row alike: no effect on alpha, and no host read-back
-        h = torch.zeros(B, H, device=dev)
-        c = torch.zeros(B, H, device=dev)
-        Hprev = torch.empty(Tn, B, H, device=dev)      # h_{t-1}
+        # every per-step result is written by its kernel straight into the slice the backward pass reads: h_t into
+        # Hall[t + 1] (so h_{t-1} of all steps is Hall[:T] and h_t of all steps Hall[1:]), c_t into Cs[t + 1]
+        Hall = torch.empty(Tn + 1, B, H, device=dev)
+        Hall[0].zero_()
+        Hprev, Hs = Hall[:Tn], Hall[1:]
         Cs = torch.empty(Tn + 1, B, H, device=dev)     # c_{t-1} at [t], c_t at [t+1]
         Cs[0].zero_()
         Ws = torch.empty(Tn, B, u.shape[1], device=dev)
         Al = torch.empty(Tn, B, B, device=dev)
         Ctx = torch.empty(Tn, B, ENC, device=dev)
         G = torch.empty(Tn, B, 4 * H, device=dev)
-        Hs = torch.empty(Tn, B, H, device=dev)
+        al_direct = (B * B) % 4 == 0                   # a [B, B] slice starts 16-byte aligned only then
+        W_wd, W_bd, w_hh_d, b_hh_d = W_w.detach(), W_b.detach(), w_hh.detach(), b_hh.detach()
         for t in range(Tn):
-            Hprev[t].copy_(h)
-            w = _lin(h, W_w, W_b)
-            alpha, cx = ops.bahdanau_attention(u, w, a_w, a_b, feats)
-            g = ops.linear(cx, w_ih_c, residual=gi_emb[t])
-            g = ops.linear(h, w_hh.detach(), b_hh.detach(), residual=g)
-            h, c = ops.lstm_pointwise(g, c)
-            Ws[t].copy_(w); Al[t].copy_(alpha); Ctx[t].copy_(cx); G[t].copy_(g); Hs[t].copy_(h); Cs[t + 1].copy_(c)
+            h = Hall[t]
+            ops.linear(h, W_wd, W_bd, out=Ws[t])
+            alpha, _ = ops.bahdanau_attention(u, Ws[t], a_w, a_b, feats, alpha_out=Al[t] if al_direct else None, ctx_out=Ctx[t])
+            if not al_direct:
+                Al[t].copy_(alpha)
+            g = ops.linear(Ctx[t], w_ih_c, residual=gi_emb[t])
+            ops.linear(h, w_hh_d, b_hh_d, residual=g, out=G[t])
+            ops.lstm_pointwise(G[t], Cs[t], h_out=Hall[t + 1], c_out=Cs[t + 1])
         hs2 = Hs.view(Tn * B, H)
         m = (masks or {}).get("dec_out")
         if m is not None:                                                           # given as [B, T, H]

@@ -550,23 +550,29 @@ def mha_core(q, k, v, heads):
     return out
 
 
-def bahdanau_attention(u, w, a_w, a_b: float, feat, want_alpha=True):
+def bahdanau_attention(u, w, a_w, a_b: float, feat, want_alpha=True, alpha_out=None, ctx_out=None):
+    """alpha_out [B, B] / ctx_out [B, E]: optional contiguous destinations (a training loop's per-step slices)."""
     B, A = u.shape
     E = feat.shape[-1]
     if tuple(w.shape) != (B, A) or a_w.numel() != A or feat.numel() != B * E:
         raise IcapError("bahdanau_attention: shape mismatch")
-    alpha = torch.empty((B, B), device=u.device, dtype=torch.float32) if want_alpha else None
-    ctx = torch.empty((B, E), device=u.device, dtype=torch.float32)
+    if (alpha_out is not None and tuple(alpha_out.shape) != (B, B)) or (ctx_out is not None and tuple(ctx_out.shape) != (B, E)):
+        raise IcapError("bahdanau_attention: alpha_out must be [B, B] and ctx_out [B, E]")
+    alpha = alpha_out if alpha_out is not None else (torch.empty((B, B), device=u.device, dtype=torch.float32) if want_alpha else None)
+    ctx = ctx_out if ctx_out is not None else torch.empty((B, E), device=u.device, dtype=torch.float32)
     N.check(N.load().icap_bahdanau_attention_f32(_ck(u, "u"), _ck(w, "w"), _ck(a_w, "a_w"), float(a_b), _ck(feat, "feat"),
                                                  _ck(alpha, "alpha"), _ck(ctx, "ctx"), B, A, E, _stream()), "bahdanau_attention")
     return alpha, ctx
 
 
-def lstm_pointwise(gates, c_in):
+def lstm_pointwise(gates, c_in, h_out=None, c_out=None):
+    """h_out / c_out [B, H]: optional contiguous destinations (a training loop's per-step slices)."""
     B, H4 = gates.shape
     H = H4 // 4
-    h = torch.empty((B, H), device=gates.device, dtype=torch.float32)
-    c = torch.empty((B, H), device=gates.device, dtype=torch.float32)
+    if (h_out is not None and tuple(h_out.shape) != (B, H)) or (c_out is not None and tuple(c_out.shape) != (B, H)):
+        raise IcapError("lstm_pointwise: h_out and c_out must be [B, H]")
+    h = h_out if h_out is not None else torch.empty((B, H), device=gates.device, dtype=torch.float32)
+    c = c_out if c_out is not None else torch.empty((B, H), device=gates.device, dtype=torch.float32)
     N.check(N.load().icap_lstm_pointwise_f32(_ck(gates, "gates"), _ck(c_in, "c_in"), _ck(h, "h"), _ck(c, "c"), B, H, _stream()),
             "lstm_pointwise")
     return h, c

@@ -195,19 +195,18 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         dout = dout.float().contiguous()
         # BatchNorm1d(V) of every step
         dpre = torch.empty(Tn * B, V, device=dev)
-        dbn_g = torch.zeros(V, device=dev); dbn_b = torch.zeros(V, device=dev)
+        DG = torch.empty(Tn, V, device=dev); DB = torch.empty(Tn, V, device=dev)     # per-step dgamma / dbeta, summed after the loop
         lib = T.N.load()
         for t in range(Tn):
             mean, rstd, s, b = bn_saved[t]
             dy_t = dout[:, t, :]
             x_t = pre[t * B:(t + 1) * B]
-            dbeta, dgamma = T.col_reduce(T.COL_BN_BWD, dy_t, x=x_t, v1=mean, v2=rstd, v3=s, v4=b)
+            dbeta, dgamma = T.col_reduce(T.COL_BN_BWD, dy_t, x=x_t, v1=mean, v2=rstd, v3=s, v4=b, out1=DB[t], out2=DG[t])
             dx_t = dpre[t * B:(t + 1) * B]
             T.N.check(lib.icap_bn_act_bwd_f32(dy_t.data_ptr(), dy_t.stride(0), x_t.data_ptr(), x_t.stride(0), s.data_ptr(), b.data_ptr(),
                                               mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ACT_NONE, B, V,
                                               dx_t.data_ptr(), dx_t.stride(0), ops._stream()), "bn_act_bwd")
-            T.axpby(dgamma, dbn_g)
-            T.axpby(dbeta, dbn_b)
+        dbn_g, dbn_b = T.col_sum(DG), T.col_sum(DB)
         dfc_w = T.gemm_tn(dpre, hd)
         dfc_b = T.col_sum(dpre)
         dhd = T.gemm_nn(dpre, fc_w.detach())

@@ -222,15 +222,19 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         dh_next = torch.zeros(B, H, device=dev)
         dc_next = torch.zeros(B, H, device=dev)
         w_ih_d, w_hh_d, W_w_d = w_ih.detach(), w_hh.detach(), W_w.detach()
+        direct = B % 4 == 0
         for t in reversed(range(Tn)):
             dh = T.axpby(dHs[t], dh_next)                                          # dh_next += dHs[t]
-            dg, dc_next = T.lstm_bwd(G[t], Cs[t], Cs[t + 1], dh, dc_next)
-            dG[t].copy_(dg)
+            dg, dc_next = T.lstm_bwd(G[t], Cs[t], Cs[t + 1], dh, dc_next, dg_out=dG[t])
             T.gemm_nn(dg, w_ih_d[:, :E], out=dEmb[t * B:(t + 1) * B])
             dctx = T.gemm_nn(dg, w_ih_d[:, E:])
             dh_prev = T.gemm_nn(dg, w_hh_d)
-            dw, da_part, dab_part = T.attention_bwd(u, Ws[t], a_w, Al[t], feats, dctx, du, dfeat, accumulate=True)
-            dWs[t].copy_(dw); dApart[t].copy_(da_part); dAb[t].copy_(dab_part)
+            if direct:      # the per-step slices start 16-byte aligned: the kernels write them in place
+                dw, _, _ = T.attention_bwd(u, Ws[t], a_w, Al[t], feats, dctx, du, dfeat, accumulate=True,
+                                           outs=(dWs[t], dApart[t], dAb[t]))
+            else:
+                dw, da_part, dab_part = T.attention_bwd(u, Ws[t], a_w, Al[t], feats, dctx, du, dfeat, accumulate=True)
+                dWs[t].copy_(dw); dApart[t].copy_(da_part); dAb[t].copy_(dab_part)
             T.gemm_nn(dw, W_w_d, out=dh_prev, accumulate=True)
             dh_next = dh_prev
         dG2 = dG.view(Tn * B, 4 * H)

@@ -219,10 +219,12 @@ def layernorm_bwd(dy, saved, gamma, post_scale=1.0):
     return dx, dgamma, dbeta
 
 
-def lstm_bwd(gates, c_in, c_out, dh, dc):
+def lstm_bwd(gates, c_in, c_out, dh, dc, dg_out=None):
+    """Returns (dgates [B, 4H], dc_prev [B, H]); dg_out: optional contiguous [B, 4H] destination of the first."""
     B, H4 = gates.shape
     H = H4 // 4
-    dg = torch.empty(B, H4, device=gates.device); dcp = torch.empty(B, H, device=gates.device)
+    dg = dg_out if dg_out is not None else torch.empty(B, H4, device=gates.device)
+    dcp = torch.empty(B, H, device=gates.device)
     N.check(N.load().icap_lstm_bwd_f32(gates.data_ptr(), c_in.data_ptr(), c_out.data_ptr(), dh.data_ptr(), _p(dc), B, H, dg.data_ptr(),
                                        dcp.data_ptr(), _stream()), "lstm_bwd")
     return dg, dcp
@@ -239,13 +241,17 @@ def gru_bwd(gi, gh, h_in, dh):
     return dgi, dgh, dhd
 
 
-def attention_bwd(u, w, a_w, alpha, feat, dctx, du, dfeat, accumulate):
-    """Returns (dw [B, A], da_part [B, A], dab_part [B]); du / dfeat are written or accumulated in place."""
+def attention_bwd(u, w, a_w, alpha, feat, dctx, du, dfeat, accumulate, outs=None):
+    """Returns (dw [B, A], da_part [B, A], dab_part [B]); du / dfeat are written or accumulated in place.
+    outs: optional (dw, da_part, dab_part) contiguous destinations."""
     B, A = u.shape
     E = feat.shape[1]
     dev = u.device
-    dscore = torch.empty(B, B, device=dev); dw = torch.empty(B, A, device=dev)
-    da_part = torch.empty(B, A, device=dev); dab_part = torch.empty(B, device=dev)
+    dscore = torch.empty(B, B, device=dev)
+    if outs is not None:
+        dw, da_part, dab_part = outs
+    else:
+        dw = torch.empty(B, A, device=dev); da_part = torch.empty(B, A, device=dev); dab_part = torch.empty(B, device=dev)
     N.check(N.load().icap_att_bwd_f32(u.data_ptr(), w.data_ptr(), a_w.data_ptr(), alpha.data_ptr(), feat.data_ptr(), dctx.data_ptr(), B, A, E,
                                       int(accumulate), dscore.data_ptr(), dw.data_ptr(), da_part.data_ptr(), dab_part.data_ptr(),
                                       du.data_ptr(), dfeat.data_ptr(), _stream()), "att_bwd")

@@ -3,6 +3,8 @@ control flow (hooks, buckets, side stream) where only one device is available.  
 Observed on the one-GPU box: completes with REH_BATCH=8 (parameters identical across ranks after 4 steps); with
 REH_BATCH=64 both ranks stall inside gloo's all-reduce of GPU tensors from the second step on, with or without hooks
 and with the device drained first - a property of this stand-in backend, which is why the run carries its own timeout.
+A later run stalled the same way at REH_BATCH=8 (first step and its exchange complete on both ranks, the second step's
+exchange never returns), so the batch size is not what decides it.
 usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/train_rehearse.py
 env: REH_OVERLAP=0|1 (hook-launched buckets), REH_SIDE_STREAM=0|1, REH_STEPS, REH_BATCH"""
 import faulthandler

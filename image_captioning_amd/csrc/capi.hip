@@ -23,6 +23,9 @@ int conv_igemm_f32(const float*, const float*, const float*, const float*, const
 int conv_igemm_tune_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, int,
                         int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int conv_igemm_tuned_cfg(int, int, int, int, int, int, int, int, int, int);
+int conv_igemm_num_cfgs();
+int conv_igemm_cfg_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int,
+                       int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int linear_argmax_parts(int);
 int linear_argmax_f32(const float*, const float*, const float*, const float*, float*, float*, int*, int, int, int, hipStream_t);
 int next_token_f32(const float*, const int*, int, long long*, int, const float*, const float*, const float*, const float*, float,
@@ -148,6 +151,15 @@ int icap_conv2d_tune_f32(const float* x, const float* w, const float* scale, con
 
 int icap_conv2d_tuned_config(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo) {
     return conv_igemm_tuned_cfg(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo);
+}
+
+int icap_conv2d_num_configs(void) { return conv_igemm_num_cfgs(); }
+
+int icap_conv2d_cfg_f32(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                        const float* gate, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                        int pad_t, int pad_l, int Ho, int Wo, int act, int cfg, void* stream) {
+    return conv_igemm_cfg_f32(x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo,
+                              act, cfg, (hipStream_t)stream);
 }
 
 int icap_linear_argmax_f32(const float* x, const float* w, const float* scale, const float* bias, float* y,

@@ -790,6 +790,22 @@ int linear_argmax_f32(const float* x, const float* w, const float* scale, const 
     return launch_cfg<64, 64, 2, 2, 1, 2, true, 1, true>(p, st);
 }
 
+// One named tile configuration on this problem (parity tests run every configuration the tuner may pick; a
+// configuration that cannot run the shape - K-step parity of the pipelined forms - returns an argument error).
+int conv_igemm_num_cfgs() { return kNumCfgs; }
+
+int conv_igemm_cfg_f32(const float* x, const float* w, const float* scale, const float* bias,
+                       const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
+                       int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                       int cfg, hipStream_t st) {
+    const int rc = validate(x, w, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo);
+    if (rc != ICAP_OK) return rc;
+    if (cfg < 0 || cfg >= kNumCfgs) { set_error("conv_igemm: configuration %d out of range [0, %d)", cfg, kNumCfgs); return ICAP_ERR_ARG; }
+    ConvParams p = make_params(x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act);
+    if (!p.vec_ok) { set_error("conv_igemm: tile configurations need Cout %% 4 == 0 and 16-byte aligned y / residual / scale / bias"); return ICAP_ERR_ALIGN; }
+    return kCfgs[cfg].fn(p, st);
+}
+
 int conv_igemm_tuned_cfg(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo) {
     std::lock_guard<std::mutex> lk(g_tuned_mu);
     auto it = g_tuned.find(ShapeKey(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo));

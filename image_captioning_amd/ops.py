@@ -227,8 +227,13 @@ def nchw_to_nhwc_pad(images: torch.Tensor, cp: int = 4) -> torch.Tensor:
     return out
 
 
-def conv2d(x, w, scale=None, bias=None, residual=None, gate=None, *, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, out=None):
-    """x [B,H,W,Cin] NHWC, w [Cout,KH,KW,Cin]; pad = (top, bottom, left, right)."""
+def conv2d_num_configs() -> int:
+    return N.load().icap_conv2d_num_configs()
+
+
+def conv2d(x, w, scale=None, bias=None, residual=None, gate=None, *, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, out=None, cfg=None):
+    """x [B,H,W,Cin] NHWC, w [Cout,KH,KW,Cin]; pad = (top, bottom, left, right).  cfg: run that tile configuration
+    (0 <= cfg < conv2d_num_configs()) instead of the heuristic / tuned one; raises when it cannot run the shape."""
     B, H, W, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
     if Cin2 != Cin:
@@ -247,6 +252,12 @@ def conv2d(x, w, scale=None, bias=None, residual=None, gate=None, *, stride=1, p
     for v, nm in ((scale, "scale"), (bias, "bias")):
         if v is not None and v.numel() != Cout:
             raise IcapError(f"conv2d: {nm} must have Cout={Cout} elements")
+    if cfg is not None:
+        N.check(N.load().icap_conv2d_cfg_f32(
+            _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"),
+            _ck(gate, "gate"), _ck(out, "out"), B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo, act, int(cfg), _stream()),
+            f"conv2d[cfg {cfg}]")
+        return out
     span = _Span("conv2d", (B, H, W, Cin, Cout, KH, stride, Ho, Wo, residual is not None, gate is not None))
     N.check(_conv_entry((B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo))(
         _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"),

@@ -70,6 +70,16 @@ int icap_conv2d_tune_f32(const float* x, const float* w, const float* scale, con
                          void* stream);
 int icap_conv2d_tuned_config(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int Ho, int Wo);
 
+/* Same computation as icap_conv2d_f32 with tile configuration `cfg` in [0, icap_conv2d_num_configs()) instead of the
+ * heuristic / tuned choice: the parity tests run every configuration the tuner may select.  Returns 1 (bad argument)
+ * when the configuration cannot run the shape (the pipelined K loops need an even number of K steps, some >= 4) and
+ * 2 when Cout % 4 != 0 (such outputs always take the one scalar-store form).  No reference counterpart. */
+int icap_conv2d_num_configs(void);
+int icap_conv2d_cfg_f32(const float* x, const float* w, const float* scale, const float* bias,
+                        const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
+                        int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                        int cfg, void* stream);
+
 /* Depthwise KSxKS convolution (KS = 3 or 5) with fused scale/bias (folded
  * BatchNorm) and activation.  w is [KS*KS][C].  When `partial` is not NULL it
  * receives per-chunk channel sums of the OUTPUT, [B][icap_dwconv_chunks(Ho,Wo,C,KS,stride)][C],

@@ -275,7 +275,7 @@ def test_fused_cells(NB, I, H):
     close(h3, R.gru_cell(w_ih[g], w_hh[g], b_ih[g], b_hh[g], x, h), what="gru_cell h")
 
 
-@pytest.mark.parametrize("M,K,N", [(256, 512, 6756), (5, 64, 100), (70, 512, 84)])
+@pytest.mark.parametrize("M,K,N", [(256, 512, 6756), (5, 64, 100), (70, 512, 84), (1024, 512, 6756), (2048, 512, 6756), (1024, 48, 6756)])
 def test_linear_argmax_and_next_token(M, K, N):
     from image_captioning_amd import ops
     d = dev()

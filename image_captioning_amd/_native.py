@@ -59,6 +59,7 @@ SIGNATURES = {
     "icap_conv2d_tune_f32": (_i, [_p] * 7 + [_i] * 13 + [_p]),
     "icap_conv2d_tuned_config": (_i, [_i] * 10),
     "icap_conv2d_num_configs": (_i, []),
+    "icap_conv2d_use_tuned": (_i, [_i]),
     "icap_conv2d_cfg_f32": (_i, [_p] * 7 + [_i] * 14 + [_p]),
     "icap_linear_argmax_f32": (_i, [_p] * 7 + [_i, _i, _i, _p]),
     "icap_linear_argmax_parts": (_i, [_i]),

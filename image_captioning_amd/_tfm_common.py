@@ -187,6 +187,7 @@ class ImageCaptioningModelBase(nn.Module):
         """Same as forward but from the CNN output [B, E]."""
         if self.training:
             from ._tfm_train import model_train_forward
+            ops.bump_weights_generation()
             return model_train_forward(self, img_embed, captions, self.dropout_masks)
         B, T = captions.shape
         E = img_embed.shape[-1]

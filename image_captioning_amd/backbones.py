@@ -28,14 +28,16 @@ from . import ops
 
 def require_eval(module: nn.Module, what: str) -> None:
     if module.training:
-        raise NotImplementedError(
-            f"{what}: only the inference forward (model.eval()) runs on the MI355X kernels; the training-mode "
-            "forward (batch-statistics BatchNorm, dropout, autograd) is not part of this build yet")
+        raise RuntimeError(
+            f"{what}: this method is the inference path and needs model.eval(); training goes through forward() / "
+            "training.Trainer (train-mode BatchNorm, dropout and the hand-written backward)")
 
 
 def _state_key(module: nn.Module):
-    """Cheap fingerprint of every parameter/buffer: changes on load_state_dict, .to(), in-place updates."""
-    key = []
+    """Cheap fingerprint of every parameter/buffer: changes on load_state_dict, .to(), in-place updates through
+    torch, and - through the generation counter - on every write the library makes by raw pointer (optimizer steps,
+    BatchNorm running statistics of a train-mode forward, replayed training graphs)."""
+    key = [ops.weights_generation()]
     for t in list(module.parameters()) + list(module.buffers()):
         key.append((t.data_ptr(), t._version))
     return tuple(key)
@@ -379,6 +381,7 @@ class CnnModel(nn.Sequential):
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         if self.training:
             from ._effnet_train import cnn_train
+            ops.bump_weights_generation()          # BatchNorm running statistics are written by raw pointer
             return cnn_train(self, images, self.dropout_masks)
         feat = self[0](images)
         lin = self[1]

@@ -24,6 +24,7 @@ int conv_igemm_tune_f32(const float*, const float*, const float*, const float*, 
                         int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int conv_igemm_tuned_cfg(int, int, int, int, int, int, int, int, int, int);
 int conv_igemm_num_cfgs();
+int conv_igemm_use_tuned(int);
 int conv_igemm_cfg_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int,
                        int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int linear_argmax_parts(int);
@@ -154,6 +155,7 @@ int icap_conv2d_tuned_config(int B, int H, int W, int Cin, int Cout, int KH, int
 }
 
 int icap_conv2d_num_configs(void) { return conv_igemm_num_cfgs(); }
+int icap_conv2d_use_tuned(int flag) { return conv_igemm_use_tuned(flag); }
 
 int icap_conv2d_cfg_f32(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
                         const float* gate, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,

@@ -647,6 +647,14 @@ static int heuristic_cfg(long long M, int Cout, long long K) {
 typedef std::tuple<int, int, int, int, int, int, int, int, int, int> ShapeKey;  // B,H,W,Cin,Cout,KH,KW,stride,Ho,Wo
 static std::map<ShapeKey, int> g_tuned;
 static std::mutex g_tuned_mu;
+static bool g_use_tuned = true;      // false: conv_igemm_f32 ignores the table (verification reruns on the heuristic choice)
+
+int conv_igemm_use_tuned(int flag) {
+    std::lock_guard<std::mutex> lk(g_tuned_mu);
+    const int prev = g_use_tuned ? 1 : 0;
+    if (flag >= 0) g_use_tuned = flag != 0;
+    return prev;
+}
 
 static int validate(const float* x, const float* w, const float* gate, float* y, int B, int H, int W, int Cin,
                     int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo) {
@@ -698,7 +706,7 @@ int conv_igemm_f32(const float* x, const float* w, const float* scale, const flo
     int cfg = -1;
     {
         std::lock_guard<std::mutex> lk(g_tuned_mu);
-        auto it = g_tuned.find(ShapeKey(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo));
+        auto it = g_use_tuned ? g_tuned.find(ShapeKey(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo)) : g_tuned.end();
         if (it != g_tuned.end()) cfg = it->second;
     }
     if (cfg < 0) cfg = heuristic_cfg(p.M, Cout, p.K);

@@ -30,7 +30,13 @@ from .training import compute_loss  # noqa: F401  (data.py:244-252: same name, H
 
 _SPLITS = [(re.compile(r"\b(can)(not)\b"), r"\1 \2"), (re.compile(r"\b(gim)(me)\b"), r"\1 \2"),
            (re.compile(r"\b(gon)(na)\b"), r"\1 \2"), (re.compile(r"\b(got)(ta)\b"), r"\1 \2"),
-           (re.compile(r"\b(lem)(me)\b"), r"\1 \2"), (re.compile(r"\b(wan)(na)(?=\s)"), r"\1 \2")]
+           (re.compile(r"\b(lem)(me)\b"), r"\1 \2"), (re.compile(r"\b(wan)(na)(?=\s|$)"), r"\1 \2")]   # NLTK pads the text with spaces first: a final 'wanna' splits too
+
+
+# What pandas.read_csv turns into NaN by default (data.py:26), and dropna(subset=['Title']) (data.py:31) then removes;
+# a whitespace-only title is not among them and stays.
+_PANDAS_NA = frozenset(["", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>",
+                        "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"])
 
 
 def custom_standardization(input_string: str) -> list[str]:
@@ -135,7 +141,7 @@ class FoodImageCaptionDataset:
         self.transform = transform
         self.max_seq_length = max_seq_length
         with open(csv_path, newline="", encoding="utf-8") as f:
-            rows = [r for r in csv.DictReader(f) if (r.get("Title") or "").strip() != ""]
+            rows = [r for r in csv.DictReader(f) if r.get("Title") is not None and r["Title"] not in _PANDAS_NA]
         self.data = []
         for r in rows:
             path = os.path.join(image_dir, f"{r['Image_Name']}.jpg")
@@ -208,13 +214,26 @@ def collate_fn(batch):
     return images, captions
 
 
-def iterate_batches(dataset, batch_size=12, shuffle=False, seed=0, collate=collate_fn, rank=0, world=1):
+def iterate_batches(dataset, batch_size=12, shuffle=False, seed=0, collate=collate_fn, rank=0, world=1, drop_last=None):
     """Minimal stand-in for the reference's ``DataLoader(..., batch_size=12, collate_fn=...)`` calls
-    (transformer_word_level.py:269-271); with world > 1 rank r takes batches r, r + world, ... ."""
+    (transformer_word_level.py:269-271); with world > 1 rank r takes batches r, r + world, ... .
+
+    Every rank must take the same number of steps (each step ends in a gradient all-reduce that all ranks join), so
+    with world > 1 the batch list is cut to a multiple of `world`.  drop_last drops a short final batch (what a
+    graph-replayed step with its fixed shapes needs); its default is True for world > 1 - ranks with different local
+    batch sizes would weight their samples differently in the averaged gradient - and False otherwise, the DataLoader
+    default the reference uses."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"iterate_batches: rank {rank} outside world {world}")
+    if drop_last is None:
+        drop_last = world > 1
     order = np.arange(len(dataset))
     if shuffle:
         order = np.random.RandomState(seed).permutation(len(dataset))
-    starts = list(range(0, len(order), batch_size))[rank::world]
+    starts = list(range(0, len(order), batch_size))
+    if drop_last and starts and len(order) - starts[-1] < batch_size:
+        starts.pop()
+    starts = starts[:len(starts) // world * world][rank::world]
     for s in starts:
         yield collate([dataset[int(i)] for i in order[s:s + batch_size]])
 

@@ -165,6 +165,21 @@ def bf16_activations_ok(cin: int, cout: int) -> bool:
     return COMPUTE_DTYPE == "bf16" and cin % 8 == 0 and cout % 4 == 0
 
 
+# Raw-pointer writes (optimizer kernels, BatchNorm running statistics, graph replays) change weights without changing
+# the tensors' (data_ptr, _version), so the eval-mode caches of kernel-layout weight copies (backbones.PreparedCache)
+# also key on this counter: everything that writes a parameter or buffer through the library advances it.
+_weights_generation = 0
+
+
+def bump_weights_generation() -> None:
+    global _weights_generation
+    _weights_generation += 1
+
+
+def weights_generation() -> int:
+    return _weights_generation
+
+
 def set_autotune(flag: bool) -> None:
     global AUTOTUNE
     AUTOTUNE = bool(flag)
@@ -225,6 +240,23 @@ def nchw_to_nhwc_pad(images: torch.Tensor, cp: int = 4) -> torch.Tensor:
     N.check(N.load().icap_nchw_to_nhwc_pad_f32(_ck(images, "images"), _ck(out, "out"), B, Cc, H, W, cp, _stream()),
             "nchw_to_nhwc_pad")
     return out
+
+
+class untuned:
+    """`with ops.untuned(): ...` - conv2d / linear run on the shape heuristic's tile configuration, whatever the tuner
+    remembered (verification reruns)."""
+
+    def __enter__(self):
+        global AUTOTUNE
+        self.prev, self.tune = N.load().icap_conv2d_use_tuned(0), AUTOTUNE
+        AUTOTUNE = False
+        return self
+
+    def __exit__(self, *exc):
+        global AUTOTUNE
+        N.load().icap_conv2d_use_tuned(self.prev)
+        AUTOTUNE = self.tune
+        return False
 
 
 def conv2d_num_configs() -> int:

@@ -4,8 +4,9 @@ Same class names, constructor arguments, ``forward`` / ``sample`` signatures and
 ``state_dict`` keys as the reference's seq2seqbasic.py:15-136, so code written
 against those classes runs unchanged; the arithmetic runs in ``libicap_hip.so``.
 
-Inference only (``model.eval()``): the training loop of the reference
-(seq2seqbasic.py:203-229) is outside this build.
+``model.eval()``: forward / sample / caption_ids run the inference kernels.  ``model.train()``: forward runs the
+train-mode kernels with a hand-written backward (``_s2s_train.py``); the loop body of seq2seqbasic.py:216-223 is
+``training.Trainer.step(..., loss="cross_entropy")``.
 """
 from __future__ import annotations
 
@@ -52,6 +53,7 @@ class EncoderCNN(nn.Module):
     def forward(self, images):
         if self.training:
             from ._s2s_train import EncoderHeadTrain, resnet_trunk_train
+            ops.bump_weights_generation()          # BatchNorm running statistics are written by raw pointer
             vgg = self.cnn_type.startswith("vgg")
             with torch.no_grad():                                       # seq2seqbasic.py:41
                 feats = self.cnn(images) if vgg else resnet_trunk_train(self.cnn, images)
@@ -107,6 +109,7 @@ class DecoderRNN(nn.Module):
         """features [B, embed], captions [B, T] -> logits [B, T, V]  (seq2seqbasic.py:59-66)."""
         if self.training:
             from ._s2s_train import decoder_train
+            ops.bump_weights_generation()
             return decoder_train(self, features, captions)
         wd = self._weights()
         B, T = captions.shape

@@ -190,6 +190,7 @@ class AdamW:
 
     def step(self) -> None:
         self.steps += 1
+        ops.bump_weights_generation()       # the kernel writes the parameters by raw pointer: eval-mode weight caches must rebuild
         f = self.flat
         lib = N.load()
         self.param_steps = [s + 1 if t else s for s, t in zip(self.param_steps, f.touched)]
@@ -213,11 +214,23 @@ class AdamW:
 
     def advance_recorded(self, touched) -> None:
         self.steps += 1
+        ops.bump_weights_generation()
         self.param_steps = [s + 1 if t else s for s, t in zip(self.param_steps, touched)]
 
     def state_dict(self):
-        return {"step": self.steps, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr, "betas": self.betas,
-                "eps": self.eps, "weight_decay": self.weight_decay}
+        return {"step": self.steps, "param_steps": list(self.param_steps), "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr,
+                "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, state) -> None:
+        """Resume: moments, the global step and the per-parameter steps (a parameter that never received a gradient has
+        its own count, which sets its bias correction)."""
+        if state["exp_avg"].numel() != self.m.numel() or len(state["param_steps"]) != len(self.param_steps):
+            raise ValueError("AdamW.load_state_dict: state belongs to a different parameter set")
+        self.m.copy_(state["exp_avg"])
+        self.v.copy_(state["exp_avg_sq"])
+        self.steps = int(state["step"])
+        self.param_steps = [int(s) for s in state["param_steps"]]
+        self.lr, self.betas, self.eps, self.weight_decay = float(state["lr"]), tuple(state["betas"]), float(state["eps"]), float(state["weight_decay"])
 
 
 class Adam(AdamW):
@@ -248,6 +261,7 @@ class SGD:
     def step(self) -> None:
         f = self.flat
         lib = N.load()
+        ops.bump_weights_generation()
         for lo, hi in f.touched_runs():
             N.check(lib.icap_axpby_f32(f.flat_g.data_ptr() + 4 * lo, -self.lr * float(f.grad_scale), 1.0, f.flat_p.data_ptr() + 4 * lo,
                                        hi - lo, _stream()), "sgd")

@@ -61,6 +61,7 @@ class TransformerEncoderBlock(nn.Module):
         batch statistics in train mode."""
         if self.training:
             from ._bah_train import encoder_block_train
+            ops.bump_weights_generation()          # BatchNorm running statistics are written by raw pointer
             return encoder_block_train(self, rows, self.dropout_masks)
         p = self._prep.get(self, self._build)
         a = p["att"]
@@ -140,6 +141,7 @@ class BahdanauDecoder(nn.Module):
             raise ValueError("BahdanauDecoder: encoder_out must hold one row per caption")
         if self.training:
             from ._bah_train import decoder_train
+            ops.bump_weights_generation()
             return decoder_train(self, captions, encoder_out.reshape(B, encoder_out.shape[-1]), self.dropout_masks)
         p = self._weights()
         feats = encoder_out.reshape(-1, encoder_out.shape[-1]).float().contiguous()

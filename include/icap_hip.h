@@ -75,6 +75,10 @@ int icap_conv2d_tuned_config(int B, int H, int W, int Cin, int Cout, int KH, int
  * when the configuration cannot run the shape (the pipelined K loops need an even number of K steps, some >= 4) and
  * 2 when Cout % 4 != 0 (such outputs always take the one scalar-store form).  No reference counterpart. */
 int icap_conv2d_num_configs(void);
+/* flag 0: icap_conv2d_f32 ignores the remembered tuning results and uses its shape heuristic (a benchmark re-runs its
+ * timed step this way to check the tuned run's output); 1: uses them again (the default); negative: query only.
+ * Returns the previous setting. */
+int icap_conv2d_use_tuned(int flag);
 int icap_conv2d_cfg_f32(const float* x, const float* w, const float* scale, const float* bias,
                         const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
                         int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,

@@ -37,6 +37,8 @@ def test_custom_standardization():
     assert d.custom_standardization("Miso-Butter Roast Chicken (2 ways)!") == ["misobutter", "roast", "chicken", "ways"]
     assert d.custom_standardization("I cannot; you wanna go, gimme 3") == ["i", "can", "not", "you", "wan", "na", "go", "gim", "me"]
     assert d.custom_standardization("  ") == []
+    assert d.custom_standardization("all i wanna") == ["all", "i", "wan", "na"]      # NLTK pads with spaces: the end of the text counts
+    assert d.custom_standardization("wannabe") == ["wannabe"]
     # the reference's pattern closes its character class at the first "]" and then splits at "|": one branch can never
     # match (a "^" anchor after a character), the other is the literal text }~] - so nothing else is ever removed, and
     # symbols outside the table become <UNK> at encode time
@@ -114,6 +116,36 @@ def test_dataset_reads_csv_and_images(tmp_path):
     assert dsc[0][1].shape == (58,) and dsc[0][1][:3].tolist() == [0, dc.char2idx["r"], dc.char2idx["o"]]
     sub = d.SubsetFoodImageCaptionDataset(ds, [1])
     assert len(sub) == 1 and sub[0][1].tolist() == cap.tolist()
+
+
+def test_dataset_title_filter_is_pandas_dropna(tmp_path):
+    """data.py:26,31: read_csv + dropna(subset=['Title']) - pandas' default NA strings go, a whitespace-only title stays."""
+    pd = pytest.importorskip("pandas")
+    Image = pytest.importorskip("PIL.Image")
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(tmp_path / "a.jpg")
+    titles = ["Roast", "NA", "null", "None", "  ", "n/a", "nan", "Soup", "", "NULL", "N/A", "na", "Null"]
+    with open(tmp_path / "t.csv", "w", encoding="utf-8") as f:
+        f.write(",Title,Ingredients,Image_Name\n" + "".join(f"{i},{t},x,a\n" for i, t in enumerate(titles)))
+    want = pd.read_csv(tmp_path / "t.csv").dropna(subset=["Title"])["Title"].tolist()
+    ds = d.FoodImageCaptionDataset(str(tmp_path / "t.csv"), str(tmp_path))
+    assert [r["Title"] for r in ds.data] == want
+    assert [r["Title"] for r in dc.FoodImageCaptionDataset(str(tmp_path / "t.csv"), str(tmp_path)).data] == want
+
+
+@pytest.mark.parametrize("n,bs,world", [(7, 1, 4), (25, 4, 2), (12, 4, 3), (5, 2, 1), (3, 4, 2)])
+def test_iterate_batches_gives_every_rank_the_same_number_of_steps(n, bs, world):
+    """Each training step ends in an all-reduce all ranks join: unequal step counts would leave ranks waiting forever."""
+    data = list(range(n))
+    per_rank = [list(d.iterate_batches(data, batch_size=bs, collate=list, rank=r, world=world)) for r in range(world)]
+    assert len({len(b) for b in per_rank}) == 1
+    seen = [i for b in per_rank for batch in b for i in batch]
+    assert len(seen) == len(set(seen))
+    if world > 1:
+        assert all(len(batch) == bs for b in per_rank for batch in b)          # short batches dropped by default
+    else:
+        assert sorted(seen) == data                                            # DataLoader default: nothing dropped
+    with pytest.raises(ValueError):
+        next(d.iterate_batches(data, rank=world, world=world))
 
 
 # ------------------------------------------------------------------ the resize oracle

@@ -96,6 +96,13 @@ def test_adamw_matches_torch(wd, lr):
             loss = ((model[4](model[3](model[2](h))) - yy) ** 2).mean()
             loss.backward()
             o.step()
+        if step == 2:           # resume from a checkpoint: a new model and optimizer built from the saved states
+            state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
+            assert state["param_steps"][:2] == [1, 1] and state["param_steps"][2:] == [3] * 4 and state["step"] == 3
+            resumed = _mlp().to(dev())
+            resumed.load_state_dict(mine.state_dict())
+            mine, opt = resumed, AdamW(resumed.parameters(), lr=lr * 7, weight_decay=0.0)
+            opt.load_state_dict(state)
     for a, b in zip(mine.parameters(), ref.parameters()):
         torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=2e-5, atol=2e-7)
 

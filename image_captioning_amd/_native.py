@@ -94,6 +94,8 @@ SIGNATURES = {
     "icap_gru_cell_f32": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p]),
     "icap_greedy_rnn_f32": (_i, [C.POINTER(RnnWeights), _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_rnn_ws_floats": (_ll, [_i] * 5),
+    "icap_greedy_rnn_static_ws_floats": (_i, []),
+    "icap_greedy_rnn_static_f32": (_i, [C.POINTER(RnnWeights), _p, _p, _p, _i, _i, _p]),
     "icap_greedy_tfm_f32": (_i, [C.POINTER(TfmWeights), _p, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_tfm_ws_floats": (_ll, [_i] * 4),
     "icap_greedy_bah_f32": (_i, [C.POINTER(BahWeights), _p, _i, _p, _p, _p, _p, _i, _i, _p]),

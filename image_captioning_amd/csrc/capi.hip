@@ -3,6 +3,7 @@
 // the caller's stream without touching the host in between.
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
 #include "decode.hpp"
 #include "../../include/icap_hip.h"
 
@@ -343,6 +344,46 @@ long long icap_greedy_rnn_ws_floats(int NB, int layers, int H, int I, int V) {
     const long long P = gemv_blocks(V);
     (void)I;
     return 4LL * layers * align4((long long)NB * H) + 2 * align4((long long)NB * P);
+}
+
+// ---- the same driver for callers that cannot allocate: its workspace is a fixed array in the library's device image.
+// Every GPU holds its own copy of the array at its own address, looked up once per device (hipGetSymbolAddress with that
+// device current) and kept; host code only ever uses the looked-up pointer, never the array's name.
+static __device__ __align__(256) float scratch[ICAP_GREEDY_RNN_STATIC_WS_FLOATS];
+static float* g_scratch_ptr[64];
+static std::mutex g_scratch_mu;
+
+static int static_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) { set_error("greedy_rnn_static: no current device (%s)", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) { set_error("greedy_rnn_static: hipGetSymbolAddress: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
+        g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return ICAP_OK;
+}
+
+int icap_greedy_rnn_static_ws_floats(void) { return ICAP_GREEDY_RNN_STATIC_WS_FLOATS; }
+
+int icap_greedy_rnn_static_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, int NB, int steps,
+                               void* stream) {
+    if (!w || NB <= 0 || w->layers <= 0 || w->H <= 0 || w->V <= 0) { set_error("greedy_rnn_static: bad arguments"); return ICAP_ERR_ARG; }
+    const long long need = icap_greedy_rnn_ws_floats(NB, w->layers, w->H, w->I, w->V);
+    if (need > ICAP_GREEDY_RNN_STATIC_WS_FLOATS) {
+        set_error("greedy_rnn_static: NB=%d layers=%d H=%d V=%d needs %lld workspace floats, the built-in buffer holds %d; "
+                  "use icap_greedy_rnn_f32 with a caller workspace", NB, w->layers, w->H, w->V, need, ICAP_GREEDY_RNN_STATIC_WS_FLOATS);
+        return ICAP_ERR_LIMIT;
+    }
+    float* ws = nullptr;
+    ICAP_TRY(static_scratch(&ws));
+    // the driver clears the recurrent state itself (memset of h and c on the stream) and writes the arg-max partials
+    // before reading them, so nothing a previous call left in the buffer is ever read
+    return icap_greedy_rnn_f32(w, x0, ids, logits_out, ws, NB, steps, stream);
 }
 
 int icap_greedy_rnn_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, float* ws, int NB,

@@ -670,8 +670,10 @@ def _ptr(t):
     return C.c_void_p(_ck(t, "weight"))
 
 
-def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False):
-    """wd: dict with is_lstm, w_ih/w_hh/b_ih/b_hh lists, fc_w, fc_b, in_table.  x0 [NB, I]."""
+def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, ids=None, logits=None, static_ws=False):
+    """wd: dict with is_lstm, w_ih/w_hh/b_ih/b_hh lists, fc_w, fc_b, in_table.  x0 [NB, I].
+    static_ws: the entry point whose workspace lives inside the library (nothing is allocated when `ids` - and `logits`
+    if wanted - are passed in); calls that overlap on one GPU share that workspace and must be serialised."""
     lib = N.load()
     NB, I = x0.shape
     L = len(wd["w_ih"])
@@ -684,8 +686,18 @@ def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False):
         w.b_ih[l] = _ck(wd["b_ih"][l], "b_ih"); w.b_hh[l] = _ck(wd["b_hh"][l], "b_hh")
     w.fc_w, w.fc_b, w.in_table = _ck(wd["fc_w"], "fc_w"), _ck(wd["fc_b"], "fc_b"), _ck(wd["in_table"], "in_table")
     dev = x0.device
-    ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
-    logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+    if ids is None:
+        ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+    elif tuple(ids.shape) != (NB, steps):
+        raise IcapError("greedy_rnn: ids must be [NB, steps]")
+    if want_logits and logits is None:
+        logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32)
+    elif logits is not None and tuple(logits.shape) != (steps, NB, V):
+        raise IcapError("greedy_rnn: logits must be [steps, NB, V]")
+    if static_ws:
+        N.check(lib.icap_greedy_rnn_static_f32(C.byref(w), _ck(x0, "x0"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"),
+                                               NB, steps, _stream()), "greedy_rnn_static")
+        return ids, logits
     ws = torch.empty(lib.icap_greedy_rnn_ws_floats(NB, L, H, I, V), device=dev, dtype=torch.float32)
     N.check(lib.icap_greedy_rnn_f32(C.byref(w), _ck(x0, "x0"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"),
                                     _ck(ws, "ws"), NB, steps, _stream()), "greedy_rnn")

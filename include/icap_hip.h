@@ -291,6 +291,18 @@ int icap_greedy_rnn_f32(const icap_rnn_weights* w, const float* x0, long long* i
                         int NB, int steps, void* stream);
 long long icap_greedy_rnn_ws_floats(int NB, int layers, int H, int I, int V);
 
+/* icap_greedy_rnn_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): no `ws` argument - the workspace (recurrent state h/c, arg-max partials) is a
+ * fixed ICAP_GREEDY_RNN_STATIC_WS_FLOATS-float array inside the library's device image, one copy per GPU held until the
+ * process ends; the call allocates and frees nothing.  Returns 3 (size limit) when
+ * icap_greedy_rnn_ws_floats(NB, layers, H, I, V) exceeds that size.  All calls on one GPU share the array: calls that
+ * overlap on one GPU (two streams, two threads) race - serialise them.  Results are identical to icap_greedy_rnn_f32.
+ * No counterpart in the reference. */
+#define ICAP_GREEDY_RNN_STATIC_WS_FLOATS (1 << 18)
+int icap_greedy_rnn_static_ws_floats(void);
+int icap_greedy_rnn_static_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, int NB, int steps,
+                               void* stream);
+
 typedef struct {
     int E, FF, V;
     const float* emb;                        /* caption_embedding [V][E] */

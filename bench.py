@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 1024 captioning, 256 training)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed step's token ids (untuned rerun + CPU oracle)")
+    ap.add_argument("--no-decode-b1", action="store_true", help="skip the single-caption decode-step measurement (configs[3] and the other decoders)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on fewer GPUs than ranks: gloo instead of RCCL, ranks share devices (numbers are not "
                          "results; gloo's all-reduce of GPU tensors tends to stall in the training secondary, which the deadline cuts)")
@@ -123,6 +125,159 @@ WORK = {"linear_bf16": lambda s: linear_bf16_work(s), "conv2d_bf16": lambda s: c
         "dwconv_bwd_weight": lambda s: (2.0 * s[0] * s[6] * s[7] * s[3] * s[4] * s[4], 4.0 * s[3] * s[0] * (s[1] * s[2] + s[6] * s[7]))}
 
 
+# ---------------------------------------------------------------- roofline of a whole traced step
+def launch_roof_ms(name, sig):
+    """(bound, milliseconds the launch would take AT its binding roofline): the larger of algorithmic flops / dense MFMA peak of
+    the dtype it multiplies in and algorithmic bytes / HBM peak."""
+    flops, byts = WORK[name](sig)
+    peak = BF16_MFMA_PEAK_TFLOPS if name in ("linear_bf16", "conv2d_bf16") else F32_MFMA_PEAK_TFLOPS
+    t_mfma, t_hbm = flops / (peak * 1e12) * 1e3, byts / (HBM_PEAK_GBS * 1e9) * 1e3
+    return ("mfma", t_mfma) if t_mfma >= t_hbm else ("hbm", t_hbm)
+
+
+def step_roofline(rec, step_ms):
+    """rec: (phase, name, sig, ms) of every traced launch of ONE step; step_ms: the measured time of a step.  Returns the
+    time-weighted roofline fraction of the whole step (time outside the traced launches - row kernels, gaps - counts as zero
+    work), the same per phase, and the kernel shape that loses the most time against its roofline."""
+    tot_ms = sum(r[3] for r in rec)
+    tot_roof = sum(launch_roof_ms(r[1], r[2])[1] for r in rec)
+    phases, shapes = {}, {}
+    for ph, n, sg, ms in rec:
+        bound, roof = launch_roof_ms(n, sg)
+        fl, by = WORK[n](sg)
+        d = phases.setdefault(ph, {"ms": 0.0, "roof_ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        d["ms"] += ms; d["roof_ms"] += roof; d["flops"] += fl; d["bytes"] += by; d["launches"] += 1
+        k = shapes.setdefault((n, sg), {"ms": 0.0, "roof_ms": 0.0, "n": 0, "bound": bound})
+        k["ms"] += ms; k["roof_ms"] += roof; k["n"] += 1
+    (wn, ws), wk = max(shapes.items(), key=lambda kv: kv[1]["ms"] - kv[1]["roof_ms"])
+    return {
+        "step": {"frac": tot_roof / step_ms, "traced_frac": tot_roof / tot_ms, "step_ms": step_ms, "traced_ms": tot_ms,
+                 "untraced_ms": max(step_ms - tot_ms, 0.0), "launches": len(rec),
+                 "definition": "sum over traced launches of (time at the binding roofline: max(flops/MFMA peak, bytes/HBM peak)) / step time"},
+        "phases": {ph: {"ms": d["ms"], "frac": d["roof_ms"] / d["ms"], "tflops": d["flops"] / d["ms"] / 1e9, "gbs": d["bytes"] / d["ms"] / 1e6,
+                        "launches": d["launches"]} for ph, d in phases.items()},
+        "worst": {"kernel": f"{wn}{list(ws)}", "bound": wk["bound"], "launches_per_step": wk["n"], "ms_per_step": wk["ms"],
+                  "frac": wk["roof_ms"] / wk["ms"], "lost_ms_per_step": wk["ms"] - wk["roof_ms"]},
+    }
+
+
+# ---------------------------------------------------------------- verification of what was timed
+GAP_EXEMPT = 1e-4      # ids may differ only from a step on whose top-2 logit gap is below this (BASELINE north_star)
+
+
+def verify_caption(torch, ops, model, images, ids_timed, n_oracle=16):
+    """The timed step ran tile configurations chosen by the tuner.  Check its token ids (a) for all images against a
+    rerun on the untuned (heuristic) configurations with logits kept, and (b) for the first n_oracle images against the
+    CPU oracle's prefix-re-run greedy decode on the oracle's own encoder features; ids must agree up to the first step
+    whose top-2 logit gap is below GAP_EXEMPT."""
+    from oracle import backbones_ref as BR, torch_ref as R
+    B = images.shape[0]
+    with ops.untuned():
+        feats = model.cnn_model(images)
+        ids_h, logits_h = model.greedy_ids_from_features(feats, CAPTION_LEN, want_logits=True)
+    top2 = torch.topk(logits_h, 2, dim=2).values                              # [T, B, 2]
+    gaps = (top2[..., 0] - top2[..., 1]).t().contiguous()                     # [B, T]
+    diff = ids_timed != ids_h
+    first_small = torch.where((gaps < GAP_EXEMPT).any(1), (gaps < GAP_EXEMPT).float().argmax(1), torch.full((B,), CAPTION_LEN, device=gaps.device))
+    first_diff = torch.where(diff.any(1), diff.float().argmax(1), torch.full((B,), CAPTION_LEN, device=gaps.device))
+    bad_rerun = int(((first_diff < first_small) & diff.any(1)).sum().item())     # differing at the small-gap step itself is allowed
+    res = {"rerun_untuned_images": B, "rerun_rows_differing": int(diff.any(1).sum().item()), "rerun_mismatch_outside_gap": bad_rerun,
+           "min_top2_gap": float(gaps.min().item())}
+    sd = {k: (v.detach().cpu().float() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
+    n = min(n_oracle, B)
+    bad_oracle, exempt, feat_err = 0, 0, 0.0
+    with torch.no_grad():
+        f_cpu = BR.cnn_model(sd, images[:n].detach().cpu())
+        feat_err = float(((feats[:n].cpu() - f_cpu).abs().max() / f_cpu.abs().max()).item())
+        got = ids_timed[:n].cpu().tolist()
+        for r in range(n):
+            want, lg = R.tfm_greedy(sd, f_cpu[r], 8, 8, CAPTION_LEN, 2, 3, False)
+            t2 = torch.topk(lg, 2, dim=1).values
+            g = (t2[:, 0] - t2[:, 1]).tolist()
+            for t in range(CAPTION_LEN):
+                if g[t] < GAP_EXEMPT:
+                    exempt += 1
+                    break
+                if got[r][t] != want[t]:
+                    bad_oracle += 1
+                    break
+    res.update({"oracle_images": n, "oracle_mismatch_outside_gap": bad_oracle, "oracle_rows_cut_by_gap_rule": exempt,
+                "encoder_features_max_rel_err_vs_oracle": feat_err, "gap_exempt": GAP_EXEMPT})
+    res["ok"] = bad_rerun == 0 and bad_oracle == 0 and feat_err < 1e-3
+    return res
+
+
+def verify_train(torch, ops, dev, rank, B, loss_tuned, seed_state):
+    """The training secondary's first step ran tuned tile configurations: the same step (same weights, inputs, dropout
+    seed) on the untuned configurations must give the same loss."""
+    from image_captioning_amd._bah_train import DropoutState
+    with ops.untuned():
+        _, step = build_train_step(torch, dev, rank, B)
+        DropoutState.manual_seed(seed_state)
+        loss_u = float(step())
+    del step
+    torch.cuda.empty_cache()
+    rel = abs(loss_u - loss_tuned) / max(abs(loss_u), 1e-12)
+    return {"loss_tuned": loss_tuned, "loss_untuned": loss_u, "rel_diff": rel, "ok": rel < 1e-4}
+
+
+# ---------------------------------------------------------------- one caption at a time (weight-streaming decode steps)
+DECODE_PARAMS = {"char_transformer": 0.57e6, "lstm": 7.80e6, "gru": 6.75e6, "word_transformer": 5.56e6, "bahdanau": 6.77e6}
+
+
+def decode_b1(torch, dev):
+    """BASELINE configs[3] (char-level long-sequence decode) and the other three decoders with ONE caption in flight:
+    microseconds per greedy step and the fraction of the HBM roofline that algorithmic bytes (parameters touched per step
+    x 4) / step time reaches.  Events on torch's current stream, which is the stream the drivers launch on."""
+    from image_captioning_amd import seq2seqbasic as s2s, transformer_word_level as twl, transformer_word_level_bahdnau as bah
+    from image_captioning_amd import transformercharmiguel as chr_
+    from image_captioning_amd.synthetic import seeded_state_dict
+    import torch.nn as nn
+
+    class Pass(nn.Module):
+        def forward(self, x):
+            return x
+
+    def seeded(m, seed):
+        m.load_state_dict(seeded_state_dict(m, seed=seed))
+        return m.eval().to(dev)
+
+    def timeit(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    g = torch.Generator().manual_seed(3)
+    f512, f256 = torch.randn(1, 512, generator=g).to(dev), torch.randn(1, 256, generator=g).to(dev)
+    out = {}
+    cm = seeded(chr_.ImageCaptioningModel(Pass(), chr_.TransformerEncoderBlock(512, 512, 2), chr_.TransformerDecoderBlock(512, 512, 4), embed_dim=512), 21)
+    jobs = [("char_transformer", lambda: cm.greedy_ids_from_features(f512, 58), 58)]
+    for kind in ("lstm", "gru"):
+        m = seeded(s2s.DecoderRNN(256, 512, VOCAB, num_layers=2, rnn_type=kind), 11)
+        jobs.append((kind, (lambda m=m: m.sample_ids(f256, CAPTION_LEN)), CAPTION_LEN))
+    twl.vocab_size = VOCAB
+    wm = seeded(twl.ImageCaptioningModel(Pass(), twl.TransformerEncoderBlock(512, 2048, 8), twl.TransformerDecoderBlock(512, 2048, 8), embed_dim=512), 21)
+    jobs.append(("word_transformer", lambda: wm.greedy_ids_from_features(f512, CAPTION_LEN), CAPTION_LEN))
+    bm = seeded(bah.ImageCaptioningModel(Pass(), bah.TransformerEncoderBlock(512, 512, 8, dropout=0.5), bah.BahdanauDecoder(512, 512, 512, 256, VOCAB, dropout=0.5)), 31)
+    jobs.append(("bahdanau", lambda: bm.greedy_ids_from_features(f512, CAPTION_LEN), CAPTION_LEN))
+    for name, fn, steps in jobs:
+        ms = timeit(fn)
+        us = ms * 1e3 / steps
+        gbs = DECODE_PARAMS[name] * 4 / us / 1e3
+        out[name] = {"us_per_step": us, "steps": steps, "captions_per_s": 1e3 / ms, "bytes_per_step": DECODE_PARAMS[name] * 4,
+                     "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+    out["note"] = "one caption in flight, fp32 weights, whole caption enqueued without host round trips; bytes = parameters touched per step x 4"
+    return out
+
+
+
 TRAIN_WORKLOAD = ("transformer_word_level_bahdnau: teacher-forced training step (EfficientNet-B0 train mode + encoder block + "
                   "Bahdanau LSTMCell decoder, compute_loss, backward, AdamW)")
 TRAIN_DTYPES = {"f32": "f32",
@@ -165,6 +320,7 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
     note(rank, f"train secondary: building the model, batch {B}")
     """The second half of the metric, measured after the contract's timed region on the same ranks: K training steps
     between barriers, max over ranks -> the "train" object of the JSON line."""
+    from image_captioning_amd._bah_train import DropoutState
     model, step = build_train_step(torch, dev, rank, B)
 
     def barrier():
@@ -173,10 +329,13 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
         torch.cuda.synchronize()
 
     ops.set_autotune(os.environ.get("ICAP_BENCH_NO_TUNE") != "1")
-    step()
+    DropoutState.manual_seed(1000 + rank)
+    first_loss = float(step())
     torch.cuda.synchronize()
     ops.set_autotune(False)
     note(rank, "train secondary: first step (tuning) done")
+    check = verify_train(torch, ops, dev, rank, B, first_loss, 1000 + rank) if rank == 0 else None
+    DropoutState.manual_seed(2000 + rank)
     for _ in range(2):
         step()
     barrier()
@@ -193,6 +352,8 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
     res = {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": 3,
            "images_per_step_per_gpu": B, "dtype": "f32", "scaling": "weak", "loss_last_step": float(loss),
            "workload": TRAIN_WORKLOAD, "parallelism": train_parallelism(model, world)}
+    if check is not None:
+        res["verified"], res["verification"] = check["ok"], check
     # the same trainer with bf16 products (BASELINE configs[2] names bf16), same K steps between the same barriers
     step.trainer.dtype = "bf16"
     for _ in range(2):
@@ -248,7 +409,7 @@ def with_deadline(seconds, on_timeout, fn):
             try:
                 on_timeout()
             finally:
-                os._exit(0)
+                os._exit(3)      # a stall is a failure: the line says so and so does the exit status
 
     timer = threading.Timer(seconds, fire)
     timer.daemon = True
@@ -261,6 +422,7 @@ def with_deadline(seconds, on_timeout, fn):
 
 
 T_START = time.perf_counter()
+PHASE = ["step"]      # which part of the step the traced launches belong to (set by the step function)
 
 
 def note(rank, msg):
@@ -310,7 +472,9 @@ def main():
         model = model.eval().to(dev)
 
         def step():
+            PHASE[0] = "encoder"
             feats = model.cnn_model(images)
+            PHASE[0] = "decode"
             return model.greedy_ids_from_features(feats, CAPTION_LEN)
 
     if args.breakdown:
@@ -321,15 +485,19 @@ def main():
     dom_events = []
     dom = {"name": None, "sig": None}
 
+    step_rec = []
+
     def find_dominant():
         rec = []
-        ops.set_trace(lambda n, s: rec.append((n, s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))) or rec[-1][2:])
+        ops.set_trace(lambda n, s: rec.append((PHASE[0], n, s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))) or rec[-1][3:])
         step()
         torch.cuda.synchronize()
         ops.set_trace(None)
         agg = {}
-        for n, s, e0, e1 in rec:
-            agg[(n, s)] = agg.get((n, s), 0.0) + e0.elapsed_time(e1)
+        for ph, n, s, e0, e1 in rec:
+            ms = e0.elapsed_time(e1)
+            step_rec.append((ph, n, s, ms))
+            agg[(n, s)] = agg.get((n, s), 0.0) + ms
         (n, s), _ = max(agg.items(), key=lambda kv: kv[1])
         dom["name"], dom["sig"] = n, s
 
@@ -381,6 +549,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert train or ids.shape == (B, CAPTION_LEN)
+    verified = None
+    if not train and rank == 0 and args.dtype == "f32" and not args.no_verify:
+        verified = verify_caption(torch, ops, model, images, ids)
+        note(rank, f"verification of the timed step's ids: {verified}")
 
     # Secondary, after the contract's timed region: the same captioning step in the opt-in bf16-product mode (fp32
     # accumulation and storage), same K steps and barriers, reported beside the fp32 headline as "bf16_mode".
@@ -421,6 +593,7 @@ def main():
         roof["kernel"] = f"{dom['name']}{list(dom['sig'])}"
         roof["traffic"] = pmc_traffic(roof["kernel"])
         roof["avg_launch_ms"] = dom_ms
+        roof.update(step_roofline(step_rec, elapsed / args.steps * 1e3))
         if train:
             workload = TRAIN_WORKLOAD
             par = train_parallelism(model, world) + (", step replayed from HIP graphs" if args.graph else "")
@@ -437,8 +610,14 @@ def main():
                        "vocab": VOCAB, "weights": "seeded random init", "parallelism": par},
             "roofline": roof,
         }
+        if verified is not None:
+            out["verified"] = verified["ok"]
+            out["verification"] = verified
         if alt is not None:
             out["bf16_mode"] = alt
+        if not train and world == 1 and not args.no_decode_b1:
+            out["decode_b1"] = decode_b1(torch, dev)
+            note(rank, "single-caption decode steps measured")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_train_baseline(torch, model, min(B, 12)) if train else cpu_baseline(torch, model, args.cpu_sample)
 
@@ -464,6 +643,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and (out.get("verified") is False or "error" in (out.get("train") or {}) or (out.get("train") or {}).get("verified") is False):
+        sys.exit(3)              # the line is printed either way; a failed check or secondary must not look like success
 
 
 def pmc_traffic(kernel):
@@ -478,33 +659,47 @@ def pmc_traffic(kernel):
 
 
 def breakdown(torch, ops, step, B):
+    """Per-launch table of one step (after tuning) and the step's roofline summary computed from it - the same
+    numbers the JSON line carries as roofline.step / phases / worst."""
     ops.set_autotune(True)
     for _ in range(2):
         step()
     ops.set_autotune(False)
     torch.cuda.synchronize()
-    rec = []
-    ops.set_trace(lambda n, s: rec.append((n, s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))) or rec[-1][2:])
     t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    step_ms = (time.perf_counter() - t0) / 5 * 1e3
+    rec = []
+    ops.set_trace(lambda n, s: rec.append((PHASE[0], n, s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))) or rec[-1][3:])
     step()
     torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) * 1e3
     ops.set_trace(None)
-    rows, tot = [], 0.0
-    for n, s, e0, e1 in rec:
-        ms = e0.elapsed_time(e1)
-        fl, by = WORK[n](s)
-        rows.append((ms, n, s, fl / ms / 1e9, by / ms / 1e6))
-        tot += ms
-    print(f"step wall {wall:.3f} ms, traced launches {len(rec)} sum {tot:.3f} ms, batch {B}")
+    rows = [(ph, n, s, e0.elapsed_time(e1)) for ph, n, s, e0, e1 in rec]
+    print(f"step {step_ms:.3f} ms (untraced mean of 5), traced launches {len(rows)} sum {sum(r[3] for r in rows):.3f} ms, batch {B}")
     lib = __import__("image_captioning_amd._native", fromlist=["load"]).load()
-    for ms, n, s, tf, gbs in rows:
+    for ph, n, s, ms in rows:
+        fl, by = WORK[n](s)
+        bound, roof = launch_roof_ms(n, s)
         cfg = ""
         if n == "conv2d":
             cfg = f" cfg={lib.icap_conv2d_tuned_config(s[0], s[1], s[2], s[3], s[4], s[5], s[5], s[6], s[7], s[8])}"
         elif n == "linear":
             cfg = f" cfg={lib.icap_conv2d_tuned_config(s[0], 1, 1, s[1], s[2], 1, 1, 1, 1, 1)}"
-        print(f"{ms:9.4f} ms  {tf:8.2f} TFLOP/s {gbs:9.1f} GB/s  {n}{list(s)}{cfg}")
+        print(f"{ms:9.4f} ms  {fl / ms / 1e9:8.2f} TFLOP/s {by / ms / 1e6:9.1f} GB/s  {bound:4s} {roof / ms:5.3f}  {ph:7s} {n}{list(s)}{cfg}")
+    print("roofline summary: " + json.dumps(step_roofline(rows, step_ms)))
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(torch, model, n):
@@ -522,7 +717,7 @@ def cpu_baseline(torch, model, n):
         for f in feats:
             R.tfm_greedy(sd, f, 8, 8, CAPTION_LEN, 2, 3, False)
         dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "captions/s", "cores": threads, "kind": "port",
+    return {"value": n / dt, "unit": "captions/s", "cores": threads, "kind": "port", "host_cpu": host_cpu_model(),
             "sample": f"{n} synthetic 224x224 images: oracle EfficientNet-B0 (batches of 16) + per-image prefix-re-run greedy decode, "
                       f"{CAPTION_LEN} tokens, fp32, torch CPU with {threads} threads, {dt:.1f} s"}
 
@@ -555,7 +750,7 @@ def cpu_train_baseline(torch, model, B):
     for _ in range(2):
         one()
     dt = (time.perf_counter() - t0) / 2
-    return {"value": B / dt, "unit": "imgs/s", "cores": threads, "kind": "port",
+    return {"value": B / dt, "unit": "imgs/s", "cores": threads, "kind": "port", "host_cpu": host_cpu_model(),
             "sample": f"2 training steps of {B} synthetic images x {CAPTION_LEN} tokens (dropout masks omitted), oracle forward + torch "
                       f"autograd + torch.optim.AdamW, fp32, torch CPU with {threads} threads, {dt:.1f} s per step"}
 

@@ -134,6 +134,8 @@ SIGNATURES = {
     "icap_maxpool2d_bf16": (_i, [_p, _p] + [_i] * 9 + [_p]),
     "icap_adaptive_avgpool2d_bf16_f32": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "icap_resize_normalize_ws_bytes": (C.c_longlong, [_i, _i, _i]),
+    "icap_augment_ws_bytes": (C.c_longlong, [_i]),
+    "icap_augment_u8": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "icap_resize_normalize_u8_f32": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "icap_im2col_f32": (_i, [_p] + [_i] * 11 + [_p, _p]),
 }

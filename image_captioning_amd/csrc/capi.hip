@@ -44,6 +44,8 @@ int linear_bf16_argmax_f32(const float*, const unsigned short*, const float*, co
 int topk_sample_f32(const float*, int, int, int, int, unsigned long long, unsigned long long, float*, int*, long long*, int, hipStream_t);
 int nchw_to_nhwc_pad_f32(const float*, float*, int, int, int, int, int, hipStream_t);
 long long resize_normalize_ws_bytes(int, int, int);
+long long augment_ws_bytes(int);
+int augment_u8(const unsigned char*, int, int, int, const int*, const float*, unsigned long long*, unsigned char*, hipStream_t);
 int resize_normalize_u8_f32(const unsigned char*, int, int, int, const int*, const int*, int, const int*, const int*, int, int, int,
                             const float*, unsigned*, float*, int, hipStream_t);
 int dwconv2d_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
@@ -664,6 +666,12 @@ int icap_maxpool2d_bf16(const unsigned short* x, unsigned short* y, int B, int H
 
 int icap_adaptive_avgpool2d_bf16_f32(const unsigned short* x, float* y, int B, int H, int W, int C, int OH, int OW, void* stream) {
     return adaptive_avgpool2d_bf16_f32(x, y, B, H, W, C, OH, OW, (hipStream_t)stream);
+}
+
+long long icap_augment_ws_bytes(int B) { return augment_ws_bytes(B); }
+int icap_augment_u8(const unsigned char* src, int B, int H, int W, const int* params, const float* contrast, void* ws,
+                    unsigned char* dst, void* stream) {
+    return augment_u8(src, B, H, W, params, contrast, static_cast<unsigned long long*>(ws), dst, (hipStream_t)stream);
 }
 
 long long icap_resize_normalize_ws_bytes(int B, int H, int Wo) { return resize_normalize_ws_bytes(B, H, Wo); }

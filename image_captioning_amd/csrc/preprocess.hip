@@ -207,4 +207,82 @@ int resize_normalize_u8_f32(const unsigned char* src, int B, int H, int W, const
     return launch_status("resize_normalize");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The random augmentations of the same transform for GIVEN per-image parameters (data.py:167-169, datachar.py:125-127:
+// RandomHorizontalFlip, RandomRotation(20), ColorJitter(contrast=0.3) - on a PIL image, i.e. Pillow's
+// transpose(FLIP_LEFT_RIGHT), rotate(angle, NEAREST, fillcolor=0) and ImageEnhance.Contrast), bit-exact; the draws
+// themselves are the caller's.
+//
+//   pass 1  geometry: destination (x, y) takes the source pixel (sx, sy) = ((a2 + x*a0 + y*a1) >> 16, (a5 + x*a3 + y*a4) >> 16)
+//           of the (optionally mirrored) image - Pillow's 16.16 fixed-point NEAREST affine pass, the caller supplies the
+//           six integers - or 0 when the source lies outside; the luma (19595 r + 38470 g + 7471 b + 32768) >> 16 of
+//           every result pixel is summed per image (integer atomics: the sum does not depend on the order).
+//   pass 2  contrast: mean = int(sum / (H*W) + 0.5); v = mean + factor * (v - mean) in fp32 without contraction,
+//           truncated for 0 <= factor <= 1, else clipped to [0, 255] and truncated (Pillow's ImagingBlend).
+struct AugParams { int flip, a0, a1, a2, a3, a4, a5, pad; };
+
+__global__ __launch_bounds__(256) void augment_geom_kernel(const unsigned char* __restrict__ src, const AugParams* __restrict__ prm,
+                                                           unsigned char* __restrict__ dst, unsigned long long* __restrict__ sums,
+                                                           int H, int W, int blocks_per_image) {
+    const int b = blockIdx.x / blocks_per_image;
+    const int i = (blockIdx.x % blocks_per_image) * 256 + threadIdx.x;
+    const AugParams q = prm[b];
+    unsigned luma = 0;
+    if (i < H * W) {
+        const int y = i / W, x = i - y * W;
+        const long long fx = (long long)q.a2 + (long long)x * q.a0 + (long long)y * q.a1;
+        const long long fy = (long long)q.a5 + (long long)x * q.a3 + (long long)y * q.a4;
+        long long sx = fx >> 16;
+        const long long sy = fy >> 16;
+        unsigned r = 0, g = 0, bl = 0;
+        if (sx >= 0 && sx < W && sy >= 0 && sy < H) {
+            if (q.flip) sx = W - 1 - sx;
+            const unsigned char* s = src + (((size_t)b * H + (size_t)sy) * W + (size_t)sx) * 3;
+            r = s[0]; g = s[1]; bl = s[2];
+        }
+        unsigned char* d = dst + ((size_t)b * H * W + (size_t)i) * 3;
+        d[0] = (unsigned char)r; d[1] = (unsigned char)g; d[2] = (unsigned char)bl;
+        luma = (r * 19595u + g * 38470u + bl * 7471u + 0x8000u) >> 16;
+    }
+    __shared__ unsigned part[4];
+    unsigned v = luma;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sums[b], (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
+}
+
+__global__ __launch_bounds__(256) void augment_contrast_kernel(unsigned char* __restrict__ img, const unsigned long long* __restrict__ sums,
+                                                               const float* __restrict__ factor, long long per_image, long long pixels) {
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_image) return;
+    const float mean = (float)(int)((double)sums[b] / (double)pixels + 0.5);
+    const float f = factor[b];
+    unsigned char* p = img + (size_t)b * per_image + i;
+    const float t = mean + f * ((float)(int)*p - mean);
+    int o;
+    if (f >= 0.f && f <= 1.f) o = (int)t;
+    else o = t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
+    *p = (unsigned char)o;
+}
+
+long long augment_ws_bytes(int B) { return 8LL * B; }
+
+// src, dst uint8 [B][H][W][3] (dst != src); params int32 [B][8] = flip, a0..a5, 0; contrast fp32 [B]; ws augment_ws_bytes(B).
+int augment_u8(const unsigned char* src, int B, int H, int W, const int* params, const float* contrast, unsigned long long* ws,
+               unsigned char* dst, hipStream_t st) {
+    if (!src || !params || !contrast || !ws || !dst || B <= 0 || H <= 0 || W <= 0) { set_error("augment: bad arguments"); return ICAP_ERR_ARG; }
+    if (src == dst) { set_error("augment: the geometric pass cannot run in place"); return ICAP_ERR_ARG; }
+    if (H > 16384 || W > 16384 || B > 65535) { set_error("augment: image %dx%d or batch %d beyond 16384 x 16384 x 65535", H, W, B); return ICAP_ERR_LIMIT; }
+    if (((uintptr_t)params & 3) || ((uintptr_t)ws & 7)) { set_error("augment: params / ws misaligned"); return ICAP_ERR_ALIGN; }
+    hipError_t e = hipMemsetAsync(ws, 0, 8ULL * B, st);
+    if (e != hipSuccess) { set_error("augment: memset: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
+    const int bpi = (H * W + 255) / 256;
+    hipLaunchKernelGGL(augment_geom_kernel, dim3((unsigned)(B * (long long)bpi)), dim3(256), 0, st, src, reinterpret_cast<const AugParams*>(params), dst, ws, H, W, bpi);
+    const long long per = 3LL * H * W;
+    hipLaunchKernelGGL(augment_contrast_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, dst, ws, contrast, per, (long long)H * W);
+    return launch_status("augment");
+}
+
 }  // namespace icap

@@ -5,8 +5,10 @@ dataset classes, the train / validation / test split, and the metrics ``compute_
 
 What differs, on purpose:
 
-* ``image_transforms`` is the deterministic tail only (Resize + ToTensor + Normalize, data.py:170-172) and runs on the
-  GPU (``preprocess.resize_normalize``); the random flip / rotation / contrast jitter (data.py:167-169) are not drawn.
+* ``image_transforms`` runs on the GPU.  By default it is the deterministic tail only (Resize + ToTensor + Normalize,
+  data.py:170-172, ``preprocess.resize_normalize``), so evaluation inputs are reproducible; the reference's random
+  flip / rotation / contrast jitter (data.py:167-169, ``preprocess.augment``) are applied with ``augment=True`` or, for
+  everything that goes through ``collate_fn``, by setting the module switch ``AUGMENT = True`` (training loaders).
 * the dataset returns decoded uint8 pixels and the collate function batches same-sized images through one resize
   launch; there is no per-item ``print`` (data.py:54).
 * ``custom_standardization`` ends in NLTK's ``word_tokenize`` in the reference.  After lower-casing and removing
@@ -126,9 +128,18 @@ def train_val_test_indices(n: int):
     return tr, va[va2], va[te]
 
 
-def image_transforms(u8_images, size: int = 224) -> torch.Tensor:
-    """Deterministic part of data.py:166-173 on the GPU: uint8 [B, H, W, 3] -> fp32 [B, 3, size, size]."""
-    from .preprocess import resize_normalize
+def image_transforms(u8_images, size: int = 224, augment=False) -> torch.Tensor:
+    """data.py:166-173 on the GPU: uint8 [B, H, W, 3] -> fp32 [B, 3, size, size].
+
+    augment=False (default): only the deterministic tail (Resize, ToTensor, Normalize) - reproducible inputs.
+    augment=True: the reference's behaviour - RandomHorizontalFlip(0.5), RandomRotation(20), ColorJitter(contrast=0.3)
+    drawn per image from torch's global generator (``preprocess.draw_augment_params``), then the tail.
+    augment=(flips, angles, factors): those parameters, one per image."""
+    from .preprocess import augment as run_augment, draw_augment_params, resize_normalize
+    if augment is not False and augment is not None:
+        n = u8_images.shape[0] if getattr(u8_images, "ndim", 4) == 4 else 1
+        flips, angles, factors = draw_augment_params(n) if augment is True else augment
+        u8_images = run_augment(u8_images, flips, angles, factors)
     return resize_normalize(u8_images, size=size)
 
 
@@ -187,9 +198,13 @@ class SubsetFoodImageCaptionDataset:
         return self.full_dataset[self.indices[idx]]
 
 
+AUGMENT = False      # True: collate_fn draws the reference's random augmentations for every decoded image it batches
+
+
 def _stack_images(images):
-    """Tensors (already transformed) are stacked; decoded uint8 arrays are grouped by size, each group resized and
-    normalised by one launch, and put back in batch order."""
+    """Tensors (already transformed) are stacked; decoded uint8 arrays are grouped by size, each group (augmented when
+    AUGMENT is set, parameters drawn in batch order, and) resized and normalised by one launch, and put back in batch
+    order."""
     if all(isinstance(im, torch.Tensor) and im.dtype != torch.uint8 for im in images):
         return torch.stack(list(images))
     arrs = [np.asarray(im.cpu()) if isinstance(im, torch.Tensor) else np.asarray(im) for im in images]
@@ -197,8 +212,13 @@ def _stack_images(images):
     for i, a in enumerate(arrs):
         groups[a.shape].append(i)
     out = None
+    drawn = None
+    if AUGMENT:
+        from .preprocess import draw_augment_params
+        drawn = draw_augment_params(len(arrs))
     for idxs in groups.values():
-        t = image_transforms(np.stack([arrs[i] for i in idxs]))
+        aug = tuple([v[i] for i in idxs] for v in drawn) if drawn is not None else False
+        t = image_transforms(np.stack([arrs[i] for i in idxs]), augment=aug)
         if out is None:
             out = torch.empty((len(arrs),) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
         out[torch.tensor(idxs, device=t.device)] = t

@@ -495,6 +495,17 @@ long long icap_dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K);
  * dX = dY W (the backward of every nn.Linear / Conv2d on the path, e.g. transformer_word_level_bahdnau.py:188-196). */
 int icap_transpose_f32(const float* src, int rows, int cols, int ld_src, float* dst, void* stream);
 
+/* The random augmentations of the reference's image transform for caller-supplied per-image parameters, on decoded
+ * uint8 pixels ahead of icap_resize_normalize_u8_f32: RandomHorizontalFlip, RandomRotation(20) (Pillow rotate: NEAREST, no
+ * expansion, zero fill) and ColorJitter(contrast=0.3) (Pillow ImageEnhance.Contrast) - data.py:167-169,
+ * datachar.py:125-127 - bit-exact against Pillow for the same parameters.  src, dst uint8 [B][H][W][3], dst != src;
+ * params int32 [B][8] = {flip, a0, a1, a2, a3, a4, a5, 0} with the 16.16 fixed-point coefficients of Pillow's affine
+ * pass (source x = (a2 + x*a0 + y*a1) >> 16, source y = (a5 + x*a3 + y*a4) >> 16); contrast fp32 [B] (1 = unchanged);
+ * ws: icap_augment_ws_bytes(B) bytes, 8-byte aligned. */
+long long icap_augment_ws_bytes(int B);
+int icap_augment_u8(const unsigned char* src, int B, int H, int W, const int* params, const float* contrast, void* ws,
+                    unsigned char* dst, void* stream);
+
 /* Deterministic tail of the image transform (data.py:170-172, datachar.py:129-131: Resize((224, 224)) of a PIL image =
  * Pillow's BILINEAR resampler - separable triangle filter, 22-bit fixed-point taps, 8-bit intermediate after the
  * horizontal pass - then ToTensor and Normalize), bit-exact.  src [B][H][W][3] uint8 (decoded RGB, all B images of one

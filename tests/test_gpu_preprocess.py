@@ -128,3 +128,66 @@ def test_evaluate_model_harness():
     assert bleu["BLEU-1"] == pytest.approx(np.mean(b1)) and set(bleu) == {"BLEU-1", "BLEU-2", "BLEU-3", "BLEU-4"}
     with pytest.raises(ValueError):
         evaluation.evaluate_model(model, [], D, idx2word, None, loss_fn, 0)
+
+
+# ------------------------------------------------------------------ augmentations (data.py:167-169) on the GPU
+def test_augment_kernel_is_bit_exact_on_the_pillow_fixture():
+    from image_captioning_amd.preprocess import augment
+    g = H.load("pil_augment")
+    for i, (h, w, flip) in enumerate(g["cases"]):
+        got = augment(g[f"in{i}"], [bool(flip)], [float(g["angles"][i])], [float(g["contrasts"][i])])
+        assert got.is_cuda and got.dtype == torch.uint8
+        assert np.array_equal(got[0].cpu().numpy(), g[f"out{i}"]), (i, h, w)
+
+
+def test_augment_kernel_batches_with_per_image_parameters():
+    """A batch of dataset-sized images, every image its own flip / angle / factor, against the numpy restatement
+    (pinned by Pillow on the CPU side); then the whole transform: augment -> resize -> normalise."""
+    from oracle import pil_augment_ref as A
+    from oracle import pil_resize_ref as R
+    from image_captioning_amd import data as d
+    from image_captioning_amd.preprocess import augment
+    rng = np.random.default_rng(21)
+    B, Hh, W = 9, 169, 274
+    imgs = rng.integers(0, 256, (B, Hh, W, 3), dtype=np.uint8)
+    imgs[::2] = (np.add.outer(np.arange(Hh) * 2, np.arange(W) * 3)[None, ..., None] % 256).astype(np.uint8)
+    flips = [bool(v) for v in rng.integers(0, 2, B)]
+    angles = [float(v) for v in rng.uniform(-20, 20, B)]
+    factors = [float(v) for v in rng.uniform(0.7, 1.3, B)]
+    angles[0], factors[0], flips[0] = 0.0, 1.0, False                      # identity
+    angles[1] = 180.0
+    got = augment(imgs, flips, angles, factors).cpu().numpy()
+    assert np.array_equal(got[0], imgs[0])
+    for i in range(B):
+        assert np.array_equal(got[i], A.augment(imgs[i], flips[i], angles[i], factors[i])), i
+    x = d.image_transforms(imgs, augment=(flips, angles, factors))
+    for i in range(B):
+        want = R.to_tensor_normalize(R.resize_bilinear_u8(A.augment(imgs[i], flips[i], angles[i], factors[i])))
+        assert np.array_equal(x[i].cpu().numpy(), want), i
+
+
+def test_collate_draws_augmentations_when_switched_on():
+    from image_captioning_amd import data as d
+    rng = np.random.default_rng(2)
+    imgs = [rng.integers(0, 256, (20, 30, 3), dtype=np.uint8) for _ in range(4)]
+    caps = [torch.tensor([2, 5, 3])] * 4
+    plain, _ = d.collate_fn(list(zip(imgs, caps)))
+    d.AUGMENT = True
+    try:
+        torch.manual_seed(1)
+        a1, _ = d.collate_fn(list(zip(imgs, caps)))
+        torch.manual_seed(1)
+        a2, _ = d.collate_fn(list(zip(imgs, caps)))
+        a3, _ = d.collate_fn(list(zip(imgs, caps)))
+    finally:
+        d.AUGMENT = False
+    assert torch.equal(a1, a2) and not torch.equal(a1, plain) and not torch.equal(a1, a3)
+
+
+def test_augment_argument_errors():
+    from image_captioning_amd.ops import IcapError
+    from image_captioning_amd.preprocess import augment
+    with pytest.raises(IcapError):
+        augment(np.zeros((2, 4, 4, 3), np.uint8), [False], [0.0], [1.0])
+    with pytest.raises(IcapError):
+        augment(np.zeros((1, 4, 4, 3), np.float32), [False], [0.0], [1.0])

@@ -191,3 +191,32 @@ def test_transformer_training_oracle_matches_reference(name):
             torch.testing.assert_close(sd[k[5:]].grad, torch.from_numpy(g[k]), rtol=2e-3, atol=1e-6, msg=lambda m: f"{k}: {m}")
         elif k.startswith("grad."):
             assert sd[k[5:]].grad is None, k                 # the decoder's unused attention / layer_norm1
+
+
+def test_oracle_on_reference_written_checkpoints():
+    """tests/golden/ref_ckpt_*.pth were saved by the reference's classes with torch's default initialisation
+    (oracle/make_golden_ckpt.py); the oracle must reproduce the reference's stored logits from them."""
+    import os
+    io = H.load("ref_ckpt_io")
+
+    def sd_of(name):
+        return torch.load(os.path.join(H.GOLDEN, name), weights_only=True)
+
+    def caps(B, T, V, seed, start=2):
+        g = torch.Generator().manual_seed(seed)
+        c = torch.randint(4, V, (B, T), generator=g)
+        c[:, 0] = start
+        return c
+    with torch.no_grad():
+        E, Hh, V, L = [int(v) for v in io["s2s_dims"]]
+        got = R.seq2seq_decoder_forward(sd_of("ref_ckpt_seq2seq_lstm.pth"), H.features(4, E, 501), caps(4, 7, V, 502))
+        assert np.allclose(got.numpy(), io["s2s_logits"], rtol=1e-4, atol=1e-5)
+        E, FF, eh, dh, V = [int(v) for v in io["word_dims"]]
+        got = R.tfm_forward_features(sd_of("ref_ckpt_word_tfm.pth"), H.features(5, E, 503), caps(5, 10, V, 504), eh, dh)
+        assert np.allclose(got.numpy(), io["word_logits"], rtol=1e-4, atol=1e-5)
+        E, FF, eh, dh, V = [int(v) for v in io["char_dims"]]
+        got = R.tfm_forward_features(sd_of("ref_ckpt_char_tfm.pth"), H.features(3, E, 505), caps(3, 12, V, 506, 0), eh, dh)
+        assert np.allclose(got.numpy(), io["char_logits"], rtol=1e-4, atol=1e-5)
+        ENC, V = int(io["bah_dims"][1]), int(io["bah_dims"][4])
+        got = R.bah_forward_features(sd_of("ref_ckpt_bahdanau.pth"), H.features(4, ENC, 507), caps(4, 9, V, 508))
+        assert np.allclose(got.numpy(), io["bah_logits"], rtol=1e-4, atol=1e-5)

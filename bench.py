@@ -61,8 +61,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed step's token ids (untuned rerun + CPU oracle)")
     ap.add_argument("--no-decode-b1", action="store_true", help="skip the single-caption decode-step measurement (configs[3] and the other decoders)")
     ap.add_argument("--rehearse", action="store_true",
-                    help="multi-rank dry run on fewer GPUs than ranks: gloo instead of RCCL, ranks share devices (numbers are not "
-                         "results; gloo's all-reduce of GPU tensors tends to stall in the training secondary, which the deadline cuts)")
+                    help="multi-rank dry run on fewer GPUs than ranks: gloo instead of RCCL (which refuses two ranks on one device), ranks "
+                         "share devices, gradient buckets staged through host memory - the control flow is the multi-GPU one, the numbers are not results")
     ap.add_argument("--cpu-sample", type=int, default=384, help="images in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -334,7 +334,7 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
     torch.cuda.synchronize()
     ops.set_autotune(False)
     note(rank, "train secondary: first step (tuning) done")
-    check = verify_train(torch, ops, dev, rank, B, first_loss, 1000 + rank) if rank == 0 else None
+    check = verify_train(torch, ops, dev, rank, B, first_loss, 1000 + rank)      # every rank: the step contains the gradient exchange
     DropoutState.manual_seed(2000 + rank)
     for _ in range(2):
         step()
@@ -352,8 +352,7 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
     res = {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": 3,
            "images_per_step_per_gpu": B, "dtype": "f32", "scaling": "weak", "loss_last_step": float(loss),
            "workload": TRAIN_WORKLOAD, "parallelism": train_parallelism(model, world)}
-    if check is not None:
-        res["verified"], res["verification"] = check["ok"], check
+    res["verified"], res["verification"] = check["ok"], check                    # rank 0's own check is the one reported
     # the same trainer with bf16 products (BASELINE configs[2] names bf16), same K steps between the same barriers
     step.trainer.dtype = "bf16"
     for _ in range(2):

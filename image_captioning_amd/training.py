@@ -275,15 +275,25 @@ class GradientReducer:
     One process per GPU; every rank computes the reference's loss on its own local batch, the gradients are
     summed and divided by the world size (the optimizer applies the 1/world factor through ``grad_scale``), i.e.
     the mean of the per-rank mean losses.  Buckets are contiguous slices of the flat gradient, filled in reverse
-    parameter order by backward.  By default every bucket is reduced right after backward, from the thread that
-    called ``step`` (the exchange is 66 MB against a step of tens of milliseconds).  With ``overlap=True``
-    post-accumulate hooks launch the all-reduce of a bucket on a side stream as soon as its last gradient has been
-    accumulated, overlapping communication with the rest of backward; that launches collectives from autograd's
-    worker thread.  The CPU (gloo) tests cover both forms; the overlapped one is opt-in because it has not run over
-    RCCL yet and hides at most the ~1 ms the exchange takes.
+    parameter order by backward.
+
+    ``overlap=True`` (the default): post-accumulate hooks launch the all-reduce of a bucket as soon as its last
+    gradient has been accumulated, so the exchange of the late layers' gradients runs while backward is still working
+    on the early layers (collectives are launched from autograd's worker thread, in the same order on every rank because
+    every rank runs the same graph); ``finish`` launches whatever the hooks did not (buckets holding parameters without
+    a gradient this step) and makes the launch stream wait for all of them.  ``overlap=False`` reduces every bucket in
+    ``finish``, after backward.
+
+    Backends.  RCCL ("nccl"): ``all_reduce(async_op=True)`` runs on the process group's own stream, ordered after the
+    stream current at the call, and ``wait`` orders the current stream after it - no host blocking, no extra stream
+    here.  gloo with device tensors (rehearsals of the multi-rank control flow on fewer GPUs than ranks) is staged
+    through pinned host memory by this class: gloo's own handling of device tensors stalls when the launch stream still
+    has work queued at the call (tools/gloo_hip_allreduce_repro.py reproduces that without this package), so the bucket
+    is copied to the host on a side stream at launch time, and ``finish`` reduces the host copy and copies it back.
+    CPU tensors (the gloo unit tests) go to gloo directly.
     """
 
-    def __init__(self, flat, group=None, bucket_mb: float = 16.0, overlap: bool = False):
+    def __init__(self, flat, group=None, bucket_mb: float = 16.0, overlap: bool = True):
         import torch.distributed as dist
         self.dist = dist
         optimizer = flat.flat if isinstance(flat, (AdamW, SGD)) else flat
@@ -313,8 +323,15 @@ class GradientReducer:
             self.counts[b] += 1
         self.handles = []
         self.overlap = overlap and self.world > 1
-        self.comm_stream = torch.cuda.Stream() if (self.overlap and optimizer.flat_g.is_cuda) else None
+        on_device = optimizer.flat_g.is_cuda
+        backend = dist.get_backend(group) if dist.is_initialized() else ""
+        self.host_staged = on_device and self.world > 1 and backend == "gloo"
+        self.comm_stream = torch.cuda.Stream() if self.host_staged else None
+        self.host = [torch.empty(hi - lo, dtype=torch.float32).pin_memory() for lo, hi in self.buckets] if self.host_staged else None
+        self.staged = []
         self.launched = [False] * len(self.buckets)
+        self.launch_order = []     # bucket indices in the order their exchange was launched this step (tests, diagnostics)
+        self.hooked = 0            # how many of them were launched by hooks, i.e. while backward was still running
         if self.overlap:
             for i, p in enumerate(optimizer.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -326,6 +343,7 @@ class GradientReducer:
             b = self.bucket_of[i]
             self.pending[b] += 1
             if self.pending[b] == self.counts[b]:
+                self.hooked += 1
                 self._launch(b)
         return hook
 
@@ -333,10 +351,12 @@ class GradientReducer:
         lo, hi = self.buckets[b]
         t = self.opt.flat_g[lo:hi]
         self.launched[b] = True
-        if self.comm_stream is not None:
+        self.launch_order.append(b)
+        if self.host_staged:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                self.handles.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.host[b].copy_(t, non_blocking=True)
+            self.staged.append(b)
         else:
             self.handles.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -345,10 +365,13 @@ class GradientReducer:
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self.handles = []
+        self.staged = []
+        self.launch_order = []
+        self.hooked = 0
 
     def finish(self):
         """Call after backward: reduces whatever the hooks did not (parameters without gradient this step,
-        or overlap disabled) and waits for all buckets."""
+        or overlap disabled) and orders the launch stream after all buckets."""
         if self.world == 1:
             return
         for b in range(len(self.buckets)):
@@ -356,8 +379,13 @@ class GradientReducer:
                 self._launch(b)
         for h in self.handles:
             h.wait()
-        if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.host_staged:
+            self.comm_stream.synchronize()                       # the device-to-host copies have landed
+            for b in self.staged:                                # same order on every rank
+                self.dist.all_reduce(self.host[b], op=self.dist.ReduceOp.SUM, group=self.group)
+                lo, hi = self.buckets[b]
+                self.opt.flat_g[lo:hi].copy_(self.host[b], non_blocking=True)
+            self.staged = []
         self.handles = []
 
 
@@ -374,7 +402,7 @@ class Trainer:
     """
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, group=None, bucket_mb=16.0,
-                 loss="compute_loss", overlap=False, dtype="f32", graph=False):
+                 loss="compute_loss", overlap=None, dtype="f32", graph=False):
         import torch.distributed as dist
         if dtype not in ("f32", "bf16"):
             raise ValueError(f"Trainer: dtype must be 'f32' or 'bf16', not {dtype!r}")
@@ -384,10 +412,12 @@ class Trainer:
         self.dtype = dtype                   # "bf16": bf16 products in forward and input gradients, fp32 master weights
                                              # / accumulation / weight gradients / optimizer (ops.train_step)
         self.opt = AdamW(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        if self.graph and overlap:
+            raise ValueError("Trainer(graph=True): the gradient exchange runs between the two recorded graphs; overlap=True is not supported")
+        if overlap is None:                  # overlapped exchange unless the step is replayed from graphs (hooks do not run in a replay)
+            overlap = not self.graph
         self.reducer = GradientReducer(self.opt, group=group, bucket_mb=bucket_mb, overlap=overlap) if dist.is_available() and dist.is_initialized() else None
         self.loss_kind = loss
-        if self.graph and self.reducer is not None and self.reducer.overlap:
-            raise ValueError("Trainer(graph=True): the gradient exchange runs between the two recorded graphs; overlap=True is not supported")
 
     def _forward_backward(self, images, captions, padding_idx, exchange=True):
         exchange = exchange and self.reducer is not None

@@ -1,12 +1,17 @@
-"""Two (or more) ranks of the data-parallel training step on ONE GPU with the gloo backend: a dry run of the multi-rank
-control flow (hooks, buckets, side stream) where only one device is available.  Not a measurement.
-Observed on the one-GPU box: completes with REH_BATCH=8 (parameters identical across ranks after 4 steps); with
-REH_BATCH=64 both ranks stall inside gloo's all-reduce of GPU tensors from the second step on, with or without hooks
-and with the device drained first - a property of this stand-in backend, which is why the run carries its own timeout.
-A later run stalled the same way at REH_BATCH=8 (first step and its exchange complete on both ranks, the second step's
-exchange never returns), so the batch size is not what decides it.
+"""Two (or more) ranks of the data-parallel training step on ONE GPU with the gloo backend: a rehearsal of the multi-rank
+control flow (hooks launching buckets during backward, bucket order, the exchange, the optimizer's 1/world factor) where
+only one device is available.  Not a measurement.  RCCL refuses two ranks on one device, so gloo stands in; its device
+tensors are staged through pinned host memory by GradientReducer (gloo's own device path stalls when the launch stream
+is busy: tools/gloo_hip_allreduce_repro.py).
+
+Checks, per rank:
+  REH_SAME=1 (default): every rank trains on the SAME batch with the SAME dropout seed, so the averaged gradient equals
+      the single-process gradient bit for bit (g + g = 2g, halved exactly for 2 ranks): the parameters after REH_STEPS
+      data-parallel steps must equal those of a single-process trainer run first in the same process.
+  REH_SAME=0: ranks train on different batches; the parameters must be identical across ranks afterwards.
+
 usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/train_rehearse.py
-env: REH_OVERLAP=0|1 (hook-launched buckets), REH_SIDE_STREAM=0|1, REH_STEPS, REH_BATCH"""
+env: REH_OVERLAP=1|0, REH_GRAPH=0|1, REH_STEPS, REH_BATCH, REH_VOCAB, REH_BUCKET_MB"""
 import faulthandler
 import os
 import sys
@@ -22,36 +27,64 @@ from image_captioning_amd._bah_train import DropoutState  # noqa: E402
 from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images  # noqa: E402
 
 
-def main():
-    faulthandler.dump_traceback_later(float(os.environ.get("REH_DUMP", "25")), repeat=False, file=sys.stderr)
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
-    B = int(os.environ.get("REH_BATCH", "8"))
-    steps = int(os.environ.get("REH_STEPS", "4"))
-    model = bah.build_model(6756, dropout=0.3)
+def run(rank, same, steps, B, V, graph, overlap, bucket_mb):
+    model = bah.build_model(V, dropout=0.3)
     model.load_state_dict(seeded_state_dict(model, seed=52))
     model = model.cuda()
-    DropoutState.manual_seed(1000 + rank)
-    tr = training.Trainer(model, lr=1e-4, weight_decay=1e-5, overlap=os.environ.get("REH_OVERLAP", "0") == "1")
-    if os.environ.get("REH_SIDE_STREAM", "1") == "0":
-        tr.reducer.comm_stream = None
-    images = synthetic_images(B, seed=5 + rank).cuda()
-    caps = synthetic_captions(B, 20, 6756, 2, 3, 0, seed=7 + rank).cuda()
-    t0 = time.perf_counter()
+    DropoutState.manual_seed(1000 if same else 1000 + rank)
+    tr = training.Trainer(model, lr=1e-3, weight_decay=1e-5, overlap=overlap, graph=graph, bucket_mb=bucket_mb)
+    off = 0 if same else rank
+    batches = [(synthetic_images(B, seed=5 + off + 10 * i).cuda(), synthetic_captions(B, 8, V, 2, 3, 0, seed=7 + off + 10 * i).cuda()) for i in range(2)]
+    orders = []
     for i in range(steps):
-        loss = tr.step(images, caps, 0)
-        print(f"[r{rank} +{time.perf_counter() - t0:5.1f}s] step {i} enqueued, buckets {len(tr.reducer.buckets)}", file=sys.stderr, flush=True)
+        loss = tr.step(*batches[i % 2], 0)
+        if tr.reducer is not None:
+            orders.append((list(tr.reducer.launch_order), tr.reducer.hooked))
     torch.cuda.synchronize()
-    # every rank must hold the same parameters after the same number of steps
-    flat = tr.opt.flat.flat_p if hasattr(tr.opt.flat, "flat_p") else torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    return tr.opt.flat.flat_p.detach().clone(), float(loss), tr, orders
+
+
+def main():
+    faulthandler.dump_traceback_later(float(os.environ.get("REH_DUMP", "100")), repeat=False, file=sys.stderr)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    same = os.environ.get("REH_SAME", "1") == "1"
+    steps, B, V = int(os.environ.get("REH_STEPS", "4")), int(os.environ.get("REH_BATCH", "4")), int(os.environ.get("REH_VOCAB", "300"))
+    graph = os.environ.get("REH_GRAPH", "0") == "1"
+    overlap = None if graph else os.environ.get("REH_OVERLAP", "1") == "1"
+    bucket_mb = float(os.environ.get("REH_BUCKET_MB", "1.0"))
+    t0 = time.perf_counter()
+    ref = run(rank, same, steps, B, V, graph, overlap, bucket_mb)[0] if same else None      # no process group yet: single process
+    dist.init_process_group("gloo")
+    flat, loss, tr, orders = run(rank, same, steps, B, V, graph, overlap, bucket_mb)
+    red = tr.reducer
+    assert red is not None and red.world == world and red.host_staged and len(red.buckets) >= 3
+    ok = True
+    if overlap and not graph:
+        # hooks launched the exchange during backward: buckets go out in the order backward fills them (last parameters first)
+        # hooks launched (most of) the exchange during backward, every bucket exactly once, in the same order every step
+        hooked = (all(sorted(o) == list(range(len(red.buckets))) for o, _ in orders) and all(o == orders[0][0] for o, _ in orders)
+                  and all(2 * h >= len(red.buckets) for _, h in orders))
+        ok = ok and hooked
+        print(f"[r{rank}] launch order (first 8): {orders[0][0][:8]}, launched by hooks during backward: {orders[0][1]} of {len(red.buckets)}, "
+              f"every bucket once and same order each step: {hooked}", file=sys.stderr, flush=True)
+    if same:
+        err = float((flat - ref).abs().max())
+        scale = float(ref.abs().max())
+        ok = ok and err <= 1e-6 * scale
+        print(f"[r{rank}] data-parallel vs single-process parameters after {steps} steps: max diff {err:.3e} (max |p| {scale:.3e})", file=sys.stderr, flush=True)
     s = flat.double().sum().reshape(1).cpu()
     both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(both, s)
-    print(f"[r{rank}] loss {float(loss):.5f} param checksum {float(s):.9f} equal across ranks: {all(float(b) == float(both[0]) for b in both)}",
-          file=sys.stderr, flush=True)
+    equal = all(float(b) == float(both[0]) for b in both)
+    ok = ok and equal and loss == loss
+    print(f"[r{rank} +{time.perf_counter() - t0:5.1f}s] loss {loss:.5f} buckets {len(red.buckets)} overlap {red.overlap} graph {graph} "
+          f"parameters equal across ranks: {equal}", file=sys.stderr, flush=True)
+    dist.barrier()
     dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
+    print(f"[r{rank}] REHEARSAL {'OK' if ok else 'FAILED'}", file=sys.stderr, flush=True)
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":

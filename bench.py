@@ -267,13 +267,20 @@ def decode_b1(torch, dev):
     jobs.append(("word_transformer", lambda: wm.greedy_ids_from_features(f512, CAPTION_LEN), CAPTION_LEN))
     bm = seeded(bah.ImageCaptioningModel(Pass(), bah.TransformerEncoderBlock(512, 512, 8, dropout=0.5), bah.BahdanauDecoder(512, 512, 512, 256, VOCAB, dropout=0.5)), 31)
     jobs.append(("bahdanau", lambda: bm.greedy_ids_from_features(f512, CAPTION_LEN), CAPTION_LEN))
+    modes = {"char_transformer": "next-token table: one batched decoder pass over 81 rows, then 58 look-ups (the decoder has no self-attention or positional encoding, so logits depend on the last token and the image only)",
+             "lstm": "3 launches per step", "gru": "3 launches per step", "word_transformer": "3 launches per step", "bahdanau": "2 launches per step"}
     for name, fn, steps in jobs:
         ms = timeit(fn)
         us = ms * 1e3 / steps
         gbs = DECODE_PARAMS[name] * 4 / us / 1e3
         out[name] = {"us_per_step": us, "steps": steps, "captions_per_s": 1e3 / ms, "bytes_per_step": DECODE_PARAMS[name] * 4,
-                     "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
-    out["note"] = "one caption in flight, fp32 weights, whole caption enqueued without host round trips; bytes = parameters touched per step x 4"
+                     "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "mode": modes[name]}
+    # the char model step by step, for comparison with its table path: the step-per-launch driver and the persistent launch
+    for mode in ("steps", "persistent"):
+        ms = timeit(lambda: cm.greedy_ids_from_features(f512, 58, mode=mode))
+        out["char_transformer"][f"us_per_step_{mode}"] = ms * 1e3 / 58
+    out["note"] = ("one caption in flight, fp32 weights, whole caption enqueued without host round trips; bytes = parameters touched per step x 4; "
+                   "us_per_step of the char model's table path = caption time / 58 (its weights are read once per caption, not per step)")
     return out
 
 

@@ -98,6 +98,10 @@ SIGNATURES = {
     "icap_greedy_rnn_static_f32": (_i, [C.POINTER(RnnWeights), _p, _p, _p, _i, _i, _p]),
     "icap_greedy_tfm_f32": (_i, [C.POINTER(TfmWeights), _p, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_tfm_ws_floats": (_ll, [_i] * 4),
+    "icap_table_walk": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
+    "icap_greedy_tfm_persist_max_nb": (_i, [_i] * 3),
+    "icap_greedy_tfm_persist_ws_bytes": (_ll, [_i] * 4),
+    "icap_greedy_tfm_persist_f32": (_i, [C.POINTER(TfmWeights), _p, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_bah_f32": (_i, [C.POINTER(BahWeights), _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_bah_ws_floats": (_ll, [_i] * 5),
     "icap_ce_loss_fwd_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _ll, _i, _p, _p, _p, _p]),

@@ -27,6 +27,12 @@ from . import ops
 from .backbones import PreparedCache, require_eval
 
 MAX_LOCKSTEP = 8
+# greedy decoding by next-token table (ImageCaptioningModel._greedy_table) when the vocabulary is at most this many times
+# the caption length (one batched pass over V rows per image replaces max_len sequential passes over one row per image:
+# more rows, but a single dependent phase) and the table stays small
+TABLE_MAX_VOCAB_PER_STEP = 2
+TABLE_MAX_ROWS = 1 << 17
+_TABLE_TOKENS: dict = {}
 
 
 def _f32(t):
@@ -211,10 +217,14 @@ class ImageCaptioningModelBase(nn.Module):
             return wd
         return self._prep.get(self, build_all)
 
-    def greedy_ids_from_features(self, img_embed, max_len, want_logits=False, lockstep=None):
+    def greedy_ids_from_features(self, img_embed, max_len, want_logits=False, lockstep=None, mode=None):
         """Greedy decoding of every image as its own batch of one (the semantics of generate_caption,
         TransformerTest.py:126-164, with argmax in place of top-k sampling).  The CNN / encoder / cross-attention
-        results do not depend on the step, so they are computed once.  Returns ids [B, max_len] on the device."""
+        results do not depend on the step, so they are computed once.  Returns ids [B, max_len] on the device.
+        mode None picks by shape: "table" (vocabulary small against the caption length - the char model: one batched
+        decoder pass + look-ups), "steps" (<= lockstep captions, 2-3 launches per step), "gemm" (large batches on the
+        matrix cores); passing lockstep chooses between the last two only; "persistent" asks for the single-launch
+        decoder with LDS-resident weights."""
         require_eval(self, "ImageCaptioningModel")
         wd = self._greedy_weights()
         enc = self.encoder.forward_independent(img_embed)
@@ -222,9 +232,56 @@ class ImageCaptioningModelBase(nn.Module):
         B = ca.shape[0]
         start = torch.full((B,), self.start_token, device=ca.device, dtype=torch.int64)
         lock = MAX_LOCKSTEP if lockstep is None else lockstep
-        if B <= lock:
+        V = wd["out_w"].shape[0]
+        if mode is None:
+            table = lockstep is None and V <= TABLE_MAX_VOCAB_PER_STEP * max_len and V * B <= TABLE_MAX_ROWS
+            mode = "table" if table else ("steps" if B <= lock else "gemm")
+        if mode == "table":
+            return self._greedy_table(wd, ca, start, max_len, want_logits)
+        if mode == "persistent":
+            return self._greedy_persistent(wd, ca, start, max_len, want_logits)
+        if mode == "steps" or (mode != "gemm" and B <= lock):
             return self._greedy_small(wd, ca, start, max_len, want_logits)
         return self._greedy_gemm(wd, ca, start, max_len, want_logits)
+
+    def _greedy_table(self, wd, ca, start, max_len, want_logits):
+        """Small vocabularies (the 81-symbol char model).  The decoder never looks at earlier positions (no self-attention
+        or positional encoding is called, transformercharmiguel.py:73-80), so the logits after token v for image b are a
+        function of (v, b) alone: ONE batched decoder pass over the V x B rows LN2(emb[v] + ca[b]) gives the table
+        next[v][b], and the caption is max_len look-ups (icap_table_walk) - result-identical to running the steps one
+        after the other, without their max_len sequential launches."""
+        B, E = ca.shape
+        V = wd["out_w"].shape[0]
+        key = (V, B, str(ca.device))
+        tok = _TABLE_TOKENS.get(key)
+        if tok is None:
+            tok = _TABLE_TOKENS[key] = torch.arange(V, device=ca.device, dtype=torch.int64).repeat_interleave(B).contiguous()
+        rows, _ = ops.embedding(wd["emb"], tok)                                       # row v*B + b = emb[v]
+        x = ops.layernorm(rows, wd["ln2_g"], wd["ln2_b"], res=ca)                     # residual row (v*B + b) % B = ca[b]
+        h = ops.linear(x, wd["fc1_w"], wd["fc1_b"], act=ops.ACT_RELU)
+        f = ops.linear(h, wd["fc2_w"], wd["fc2_b"], residual=x)
+        x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
+        pv, pi, logits = ops.linear_argmax(x2, wd["out_w4"], wd["out_b4"], want_logits=want_logits)
+        nxt = torch.empty((V * B, 1), device=ca.device, dtype=torch.int64)
+        ops.next_token(pv, pi, nxt, 0)
+        ids, lg = ops.table_walk(nxt.view(V, B), start, max_len, logits_tab=logits if want_logits else None, V=V)
+        return (ids, lg) if want_logits else ids
+
+    def _greedy_persistent(self, wd, ca, start, max_len, want_logits):
+        """One persistent launch per group of captions with the step's weights resident in LDS
+        (icap_greedy_tfm_persist_f32); measured slower than the table walk for the char model and level with the
+        step-per-launch driver for the word model, so it is never chosen by default."""
+        E, FF, V = ca.shape[1], wd["fc1_w"].shape[0], wd["out_w"].shape[0]
+        nb = ops.greedy_tfm_persist_max_nb(E, FF, V)
+        if nb == 0:
+            raise ops.IcapError("persistent decoder: shape not supported")
+        ids, logits = [], []
+        for s in range(0, ca.shape[0], nb):
+            i, lg = ops.greedy_tfm_persist(wd, ca[s:s + nb].contiguous(), start[s:s + nb].contiguous(), max_len, want_logits)
+            ids.append(i)
+            logits.append(lg)
+        ids = torch.cat(ids, 0)
+        return (ids, torch.cat(logits, 1)) if want_logits else ids
 
     def _greedy_small(self, wd, ca, start, max_len, want_logits):
         ids, logits = [], []

@@ -25,6 +25,10 @@ int conv_igemm_tune_f32(const float*, const float*, const float*, const float*, 
                         int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int conv_igemm_tuned_cfg(int, int, int, int, int, int, int, int, int, int);
 int conv_igemm_num_cfgs();
+int table_walk(const long long*, const long long*, long long*, const float*, int, float*, int, int, int, hipStream_t);
+int greedy_tfm_persist_max_nb(int, int, int);
+long long greedy_tfm_persist_ws_bytes(int, int, int, int);
+int greedy_tfm_persist_f32(const icap_tfm_weights*, const float*, const long long*, long long*, float*, void*, int, int, hipStream_t);
 int conv_igemm_use_tuned(int);
 int conv_igemm_cfg_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int,
                        int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -474,6 +478,18 @@ int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long l
         ICAP_TRY(gemv_step_f32(w->out_w, nullptr, w->out_b, in3, lo, V, NB, V, E, ACT_NONE, pv, pi, st));
     }
     return argmax_finalize_f32(pv, pi, P, ids + (steps - 1), steps, nullptr, nullptr, nullptr, 0, 0, NB, st);
+}
+
+int icap_table_walk(const long long* next, const long long* start, long long* ids, const float* logits_tab, int ldl,
+                    float* logits_out, int V, int B, int steps, void* stream) {
+    return table_walk(next, start, ids, logits_tab, ldl, logits_out, V, B, steps, (hipStream_t)stream);
+}
+
+int icap_greedy_tfm_persist_max_nb(int E, int FF, int V) { return greedy_tfm_persist_max_nb(E, FF, V); }
+long long icap_greedy_tfm_persist_ws_bytes(int NB, int E, int FF, int V) { return greedy_tfm_persist_ws_bytes(NB, E, FF, V); }
+int icap_greedy_tfm_persist_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
+                                float* logits_out, void* ws, int NB, int steps, void* stream) {
+    return greedy_tfm_persist_f32(w, ca, start_ids, ids, logits_out, ws, NB, steps, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ greedy: Bahdanau LSTMCell decoder

@@ -291,6 +291,52 @@ int next_token_f32(const float* part_val, const int* part_idx, int nparts, long 
     return launch_status("next_token");
 }
 
+// ---------------------------------------------------------------- greedy decode as a walk over a next-token table
+// The transformer decoders of the reference have no self-attention and no positional encoding in use
+// (transformer_word_level.py:72-79): the logits after a token depend on that token and the image only, so greedy
+// decoding is the iteration t -> next[t] of a per-image table.  next: [V][B] (row v*B + b: the arg-max after token v
+// for image b), start [B], ids [B][steps].  One workgroup per image: its table column goes to LDS, one lane walks it,
+// then every lane copies the logits rows of the visited tokens (logits_tab [V*B][ldl] -> logits_out [steps][B][V]).
+__global__ __launch_bounds__(256) void table_walk_kernel(const long long* __restrict__ next, const long long* __restrict__ start,
+                                                         long long* __restrict__ ids, const float* __restrict__ logits_tab, int ldl,
+                                                         float* __restrict__ logits_out, int V, int B, int steps) {
+    extern __shared__ int walk_lds[];     // [V] next token of this image, then [steps] the tokens fed at each step
+    int* col = walk_lds;
+    int* fed = walk_lds + V;
+    const int b = blockIdx.x;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const long long n = next[(size_t)v * B + b];
+        col[v] = n < 0 ? 0 : (n >= V ? V - 1 : (int)n);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long s = start[b];
+        int tok = s < 0 ? 0 : (s >= V ? V - 1 : (int)s);
+        for (int t = 0; t < steps; ++t) {
+            fed[t] = tok;
+            tok = col[tok];
+            ids[(size_t)b * steps + t] = tok;
+        }
+    }
+    if (!logits_out) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < steps * V; i += 256) {
+        const int t = i / V, v = i - t * V;
+        logits_out[((size_t)t * B + b) * V + v] = logits_tab[((size_t)fed[t] * B + b) * ldl + v];
+    }
+}
+
+int table_walk(const long long* next, const long long* start, long long* ids, const float* logits_tab, int ldl, float* logits_out,
+               int V, int B, int steps, hipStream_t st) {
+    if (!next || !start || !ids || V <= 0 || B <= 0 || steps <= 0 || (logits_out && (!logits_tab || ldl < V))) {
+        set_error("table_walk: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if ((long long)(V + steps) * 4 > 60 * 1024) { set_error("table_walk: V + steps = %d exceeds the 15360 entries that fit in LDS", V + steps); return ICAP_ERR_LIMIT; }
+    hipLaunchKernelGGL(table_walk_kernel, dim3(B), dim3(256), (size_t)(V + steps) * 4, st, next, start, ids, logits_tab, ldl, logits_out, V, B, steps);
+    return launch_status("table_walk");
+}
+
 // ---------------------------------------------------------------- multi-head attention core
 // q: [Lq][N][E]  k, v: [Lk][Nk][E] with Nk == N or Nk == 1 (keys shared by every
 // batch column).  out[lq][n][h*hd + d] = sum_s softmax_s(q.k_s / sqrt(hd)) v_s.

@@ -723,6 +723,45 @@ def greedy_tfm(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, steps: int, 
     return ids, logits
 
 
+def table_walk(nxt, start, steps, logits_tab=None, V=None):
+    """nxt int64 [V, B] next-token table, start int64 [B] -> ids [B, steps] (and logits [steps, B, V] gathered from
+    logits_tab [V*B, ld] when given)."""
+    Vt, B = nxt.shape
+    V = Vt if V is None else V
+    ids = torch.empty((B, steps), device=nxt.device, dtype=torch.int64)
+    logits = torch.empty((steps, B, V), device=nxt.device, dtype=torch.float32) if logits_tab is not None else None
+    N.check(N.load().icap_table_walk(_ck(nxt, "next", torch.int64), _ck(start, "start", torch.int64), _ck(ids, "ids", torch.int64),
+                                     _ck(logits_tab, "logits_tab"), logits_tab.shape[1] if logits_tab is not None else 0,
+                                     _ck(logits, "logits"), V, B, steps, _stream()), "table_walk")
+    return ids, logits
+
+
+def greedy_tfm_persist_max_nb(E: int, FF: int, V: int) -> int:
+    """Captions per call of the persistent whole-caption decoder for this shape; 0 = not supported."""
+    return N.load().icap_greedy_tfm_persist_max_nb(E, FF, V)
+
+
+def greedy_tfm_persist(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False):
+    """greedy_tfm as one persistent launch with LDS-resident weights (icap_greedy_tfm_persist_f32).  A launch that could
+    not make progress leaves -1 in every id."""
+    lib = N.load()
+    NB, E = ca.shape
+    FF = wd["fc1_w"].shape[0]
+    V = wd["out_w"].shape[0]
+    w = N.TfmWeights()
+    w.E, w.FF, w.V = E, FF, V
+    for k in ("emb", "ln2_g", "ln2_b", "ln3_g", "ln3_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "out_w", "out_b"):
+        setattr(w, k, _ck(wd[k], k))
+    dev = ca.device
+    ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+    logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+    ws = torch.empty((lib.icap_greedy_tfm_persist_ws_bytes(NB, E, FF, V) + 7) // 8, device=dev, dtype=torch.int64)
+    N.check(lib.icap_greedy_tfm_persist_f32(C.byref(w), _ck(ca, "ca"), _ck(start_ids, "start_ids", torch.int64),
+                                            _ck(ids, "ids", torch.int64), _ck(logits, "logits"), ws.data_ptr(), NB, steps, _stream()),
+            "greedy_tfm_persist")
+    return ids, logits
+
+
 def greedy_bah(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False):
     lib = N.load()
     NB, ENC = context.shape

@@ -321,6 +321,29 @@ int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long l
                         float* logits_out, float* ws, int NB, int steps, void* stream);
 long long icap_greedy_tfm_ws_floats(int NB, int E, int FF, int V);
 
+/* Greedy decoding as a walk over a per-image next-token table.  The reference's transformer decoders use neither
+ * self-attention nor positional encoding (transformer_word_level.py:72-79, transformercharmiguel.py:73-80: only
+ * cross_attention, the FFN and output_fc are called), so the logits after a token depend on that token and the image
+ * only; for a small vocabulary (the 81-symbol char model) the whole table next[v][b] = argmax(logits(token v, image b))
+ * comes out of ONE batched pass of the decoder over V rows per image, and the T-step caption of generate_caption
+ * (TransformerTest.py:139-164, argmax form) is T look-ups.  next int64 [V][B], start int64 [B], ids int64 [B][steps];
+ * logits_out (optional) [steps][B][V] is gathered from logits_tab [V*B][ldl] (row v*B + b).  V + steps <= 15360. */
+int icap_table_walk(const long long* next, const long long* start, long long* ids, const float* logits_tab, int ldl,
+                    float* logits_out, int V, int B, int steps, void* stream);
+
+/* The same greedy decode as icap_greedy_tfm_f32 as ONE persistent launch for the whole caption: the step's weight rows are
+ * split over a grid of workgroups and stay in their LDS for all `steps`; only the activation vectors cross between
+ * workgroups (64-bit {value, tag} words polled with device-scope atomic loads - no kernel boundary and no grid barrier
+ * inside a step).  For the decoders whose per-step weights fit the chip's LDS: the char model (transformercharmiguel.py:
+ * 55-80, 2.3 MB over 32 workgroups) and the word model (transformer_word_level.py:54-79, 22 MB over 256).
+ * icap_greedy_tfm_persist_max_nb: captions per call the shape allows (0 = shape not supported: use icap_greedy_tfm_f32);
+ * ws: icap_greedy_tfm_persist_ws_bytes(NB, E, FF, V) bytes, 8-byte aligned (cleared by the call).  If a workgroup
+ * cannot make progress (the grid is not co-resident) the spin limit ends the launch and every id is written as -1. */
+int icap_greedy_tfm_persist_max_nb(int E, int FF, int V);
+long long icap_greedy_tfm_persist_ws_bytes(int NB, int E, int FF, int V);
+int icap_greedy_tfm_persist_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
+                                float* logits_out, void* ws, int NB, int steps, void* stream);
+
 typedef struct {
     int E, H, V;                             /* embed dim, decoder dim, vocab */
     const float* emb;                        /* [V][E] */

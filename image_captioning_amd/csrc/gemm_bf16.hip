@@ -48,23 +48,36 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // contribute zeros.  CONV = 1: Cin a multiple of 32, so a 32-wide K slice lies inside one filter tap.  CONV = 2: Cin = 4
 // (the channel-padded RGB image): a slice covers 8 taps, one per staging lane; the weight rows are zero-padded to a
 // multiple of 32 and taps beyond KH * KW read as zeros.
-template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, int CONV = 0>
+//
+// SPLIT = 3: fp32-accurate products on the bf16 matrix cores.  Every fp32 operand is the exact sum of three bf16 values
+// (hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid): 3 x 8 mantissa bits cover fp32's 24), so
+//   a * b = hi.hi + (hi.mid + mid.hi) + (mid.mid + hi.lo + lo.hi) + [mid.lo + lo.mid + lo.lo, each <= 2^-24 |a b|, dropped]
+// and the six kept bf16 products are exact in the MFMA's fp32 accumulation: the result differs from an fp32 dot product
+// by a few units of fp32 rounding, at 6/16 of the fp32 MFMA's cost per multiply-add (v_mfma_f32_32x32x2_f32 retires
+// 64 flop per cycle and SIMD, v_mfma_f32_32x32x16_bf16 1024).  x is split while it is staged (three LDS planes), w points
+// to three pre-split planes [3][N][K].
+template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, int CONV = 0, int SPLIT = 1>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) {
     static_assert(!(CONV && (GATE || AMAX)) && !(CONV == 2 && A16), "the convolution form has no gate / arg-max; its 4-channel form reads fp32");
+    static_assert(SPLIT == 1 || (SPLIT == 3 && !A16 && CONV == 0), "split products: fp32 activations, linear form");
     constexpr int BK = GB16_BK, LDK = GB16_LDK;
     constexpr int TM = BM / 2, TN = BN / 2, RM = TM / 32, RN = TN / 32;
     constexpr int AP = BM / 32;                    // staging passes over A: thread t -> row t/8 + 32 i, floats 4 (t%8) ..
     constexpr int BP = (BN + 63) / 64;             // staging passes over W: thread t -> row t/4 + 64 i, bf16 8 (t%4) ..
     constexpr int EP_LD = BN + 4;
     constexpr int EP_ROWS = BM < 64 ? BM : 64;
-    constexpr int STAGE_BYTES = 2 * (BM + BN) * LDK * 2;
+    constexpr int STAGE_BYTES = SPLIT * 2 * (BM + BN) * LDK * 2;
     constexpr int EP_BYTES = EP_ROWS * EP_LD * 4;
     constexpr int SMEM_BYTES = STAGE_BYTES > EP_BYTES ? STAGE_BYTES : EP_BYTES;
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is built from 32x32 blocks");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
-    unsigned short* As = reinterpret_cast<unsigned short*>(smem);            // [2][BM][LDK]
-    unsigned short* Bs = As + 2 * BM * LDK;                                  // [2][BN][LDK]
+    // the split form's three planes exceed the 64 KB of static LDS: it runs on dynamic LDS (gb16_smem_bytes)
+    __shared__ __attribute__((aligned(16))) unsigned char smem_static[SPLIT == 1 ? SMEM_BYTES : 16];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    unsigned char* smem = SPLIT == 1 ? smem_static : smem_dyn;
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem);            // [SPLIT][2][BM][LDK]
+    unsigned short* Bs = As + SPLIT * 2 * BM * LDK;                          // [SPLIT][2][BN][LDK]
+    constexpr int APL = 2 * BM * LDK, BPL = 2 * BN * LDK;                    // elements per plane
     float* ep = reinterpret_cast<float*>(smem);                              // [EP_ROWS][EP_LD], used after the K loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,15 +143,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
         b_src[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K;
     }
 
-    float4 ra[AP], rg[GATE ? AP : 1];
-    uint4 rb[BP];
+    // staging register sets: the split form keeps two K slices in flight (its workgroup is alone on the CU, so a slice
+    // needs more than one step of MFMAs to arrive), the others one
+    constexpr int NSET = SPLIT == 3 ? 2 : 1;
+    float4 ra[NSET][AP], rg[NSET][GATE ? AP : 1];
+    uint4 rb[NSET][SPLIT][BP];
     uint4 ra16[A16 ? AP16 : 1];
     float4 rg16[(A16 && GATE) ? AP16 : 1][2];
-    unsigned okmask = 0;
+    unsigned okmask_s[NSET];
     // every load is unconditional (clamped address); out-of-range elements are zeroed when the slice goes to LDS
-    auto gload = [&](int t) {
+    auto gload = [&](int t, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        unsigned okmask = 0;
         const int ka = t * BK + a_k4, kb = t * BK + b_k8;
-        okmask = 0;
         if constexpr (A16) {
 #pragma unroll
             for (int i = 0; i < AP16; ++i) {
@@ -162,18 +179,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
             if constexpr (CONV == 1) {
                 const int ih = a_ih[i] + c_kh, iw = a_iw[i] + c_kw;
                 const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ((size_t)ih * p.W + iw) * p.Cin + c_c0 + a_k4 : p.x);
+                ra[S][i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ((size_t)ih * p.W + iw) * p.Cin + c_c0 + a_k4 : p.x);
                 okmask |= ok ? (1u << i) : 0u;
             } else if constexpr (CONV == 2) {
                 const int tap = (ka >> 2), kh = tap / p.KW, kw = tap - kh * p.KW;
                 const int ih = a_ih[i] + kh, iw = a_iw[i] + kw;
                 const bool ok = a_ok[i] && tap < p.KHW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ((size_t)ih * p.W + iw) * 4 : p.x);
+                ra[S][i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ((size_t)ih * p.W + iw) * 4 : p.x);
                 okmask |= ok ? (1u << i) : 0u;
             } else {
                 const bool ok = a_ok[i] && ka < p.K;
-                ra[i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ka : p.x);
-                if (GATE) rg[i] = *reinterpret_cast<const float4*>(ok ? g_src[i] + ka : p.gate);
+                ra[S][i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ka : p.x);
+                if (GATE) rg[S][i] = *reinterpret_cast<const float4*>(ok ? g_src[i] + ka : p.gate);
                 okmask |= ok ? (1u << i) : 0u;
             }
         }
@@ -187,11 +204,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             const bool ok = b_ok[i] && kb < p.K;
-            rb[i] = *reinterpret_cast<const uint4*>(ok ? b_src[i] + kb : p.w);
+#pragma unroll
+            for (int sp = 0; sp < SPLIT; ++sp)
+                rb[S][sp][i] = *reinterpret_cast<const uint4*>(ok ? b_src[i] + (size_t)sp * p.N * p.K + kb : p.w);
             okmask |= ok ? (1u << (16 + i)) : 0u;
         }
+        okmask_s[S] = okmask;
     };
-    auto lds_store = [&](int buf) {
+    auto lds_store = [&](int buf, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        const unsigned okmask = okmask_s[S];
         if constexpr (A16) {
 #pragma unroll
             for (int i = 0; i < AP16; ++i) {
@@ -214,17 +236,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
         }
 #pragma unroll
         for (int i = 0; i < (A16 ? 0 : AP); ++i) {
-            float4 v = ra[i];
-            if (GATE) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+            float4 v = ra[S][i];
+            if (GATE) { v.x *= rg[S][i].x; v.y *= rg[S][i].y; v.z *= rg[S][i].z; v.w *= rg[S][i].w; }
+            if (!((okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 o = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
-            if (!((okmask >> i) & 1u)) o = make_uint2(0u, 0u);
             *reinterpret_cast<uint2*>(&As[(buf * BM + a_row + 32 * i) * LDK + a_k4]) = o;
+            if constexpr (SPLIT == 3) {
+                // residual after the bf16 head (exact in fp32), its bf16 head, and the residual after that
+                float4 r = make_float4(v.x - __uint_as_float(o.x << 16), v.y - __uint_as_float(o.x & 0xffff0000u),
+                                       v.z - __uint_as_float(o.y << 16), v.w - __uint_as_float(o.y & 0xffff0000u));
+                const uint2 m = make_uint2(pack_bf16(r.x, r.y), pack_bf16(r.z, r.w));
+                *reinterpret_cast<uint2*>(&As[APL + (buf * BM + a_row + 32 * i) * LDK + a_k4]) = m;
+                r = make_float4(r.x - __uint_as_float(m.x << 16), r.y - __uint_as_float(m.x & 0xffff0000u),
+                                r.z - __uint_as_float(m.y << 16), r.w - __uint_as_float(m.y & 0xffff0000u));
+                *reinterpret_cast<uint2*>(&As[2 * APL + (buf * BM + a_row + 32 * i) * LDK + a_k4]) = make_uint2(pack_bf16(r.x, r.y), pack_bf16(r.z, r.w));
+            }
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             if (BN % 64 == 0 || b_row + 64 * i < BN) {
-                const uint4 o = ((okmask >> (16 + i)) & 1u) ? rb[i] : make_uint4(0u, 0u, 0u, 0u);
-                *reinterpret_cast<uint4*>(&Bs[(buf * BN + b_row + 64 * i) * LDK + b_k8]) = o;
+#pragma unroll
+                for (int sp = 0; sp < SPLIT; ++sp) {
+                    const uint4 o = ((okmask >> (16 + i)) & 1u) ? rb[S][sp][i] : make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(&Bs[sp * BPL + (buf * BN + b_row + 64 * i) * LDK + b_k8]) = o;
+                }
             }
         }
     };
@@ -241,33 +276,67 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             const int koff = s * 16 + 8 * lh;
-            bf16x8 af[RM], bf[RN];
+            bf16x8 af[SPLIT][RM], bf[SPLIT][RN];
 #pragma unroll
-            for (int i = 0; i < RM; ++i)
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&As[(buf * BM + wm * TM + i * 32 + lr) * LDK + koff]));
+            for (int sp = 0; sp < SPLIT; ++sp) {
 #pragma unroll
-            for (int j = 0; j < RN; ++j)
-                bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[(buf * BN + wn * TN + j * 32 + lr) * LDK + koff]));
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
+                for (int i = 0; i < RM; ++i)
+                    af[sp][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&As[sp * APL + (buf * BM + wm * TM + i * 32 + lr) * LDK + koff]));
 #pragma unroll
                 for (int j = 0; j < RN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    bf[sp][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[sp * BPL + (buf * BN + wn * TN + j * 32 + lr) * LDK + koff]));
+            }
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) {
+                    if constexpr (SPLIT == 3) {   // smallest terms first; (a plane, b plane) pairs with plane sum <= 2
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                }
         }
     };
 
     const int nk = (p.K + BK - 1) / BK;
-    gload(0);
-    lds_store(0);
-    __syncthreads();
-    int cur = 0;
-    for (int t = 0; t < nk; ++t) {
-        const bool more = t + 1 < nk;
-        if (more) gload(t + 1);
-        compute(cur);
-        if (more) lds_store(cur ^ 1);
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, NSET - 1>;
+    gload(0, T0{});
+    lds_store(0, T0{});
+    if constexpr (NSET == 2) {
+        // slice t in LDS buffer t & 1, slice t + 1 in register set (t + 1) & 1, slice t + 2 fetched during step t
+        if (nk > 1) gload(1, T1{});
         __syncthreads();
-        cur ^= 1;
+        for (int t = 0; t < nk; t += 2) {
+            if (t + 2 < nk) gload(t + 2, T0{});
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < nk) lds_store(1, T1{});
+            __syncthreads();
+            if (t + 1 >= nk) break;
+            if (t + 3 < nk) gload(t + 3, T1{});
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nk) lds_store(0, T0{});
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        int cur = 0;
+        for (int t = 0; t < nk; ++t) {
+            const bool more = t + 1 < nk;
+            if (more) gload(t + 1, T0{});
+            compute(cur);
+            if (more) lds_store(cur ^ 1, T0{});
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // ---- epilogue: accumulators -> LDS (row-major) -> 16-byte stores along the output row ----
@@ -479,6 +548,91 @@ int linear_bf16_argmax_f32(const float* x, const unsigned short* w, const float*
     if (tiles > 0x7fffffffLL) { set_error("linear_bf16_argmax: problem too large"); return ICAP_ERR_LIMIT; }
     hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, p);
     return launch_status("linear_bf16_argmax");
+}
+
+// ---------------------------------------------------------------- fp32-accurate linear layers on split bf16 products
+// w3: three bf16 planes [3][N][K] made by split3_f32 from the fp32 weights.  Dynamic LDS: the three operand planes of a
+// double-buffered 128 x 128 x 32 tile take 120 KB, so one workgroup owns a CU.
+template <int BM, int BN>
+constexpr int gb16_split_smem() {
+    constexpr int stage = 3 * 2 * (BM + BN) * GB16_LDK * 2, ep = (BM < 64 ? BM : 64) * (BN + 4) * 4;
+    return stage > ep ? stage : ep;
+}
+
+template <int BM, int BN, bool GATE, bool AMAX>
+static int gb16_split_launch(GemmBf16Params& p, hipStream_t st) {
+    static hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, GATE, AMAX, false, 0, 3>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, gb16_split_smem<BM, BN>());
+    if (attr_rc != hipSuccess) { set_error("linear_f32x3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr_rc)); return ICAP_ERR_HIP_BASE + (int)attr_rc; }
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const dim3 grid((unsigned)((long long)((p.M + BM - 1) / BM) * p.tiles_n)), block(256);
+    constexpr int lds_bytes = gb16_split_smem<BM, BN>();
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, GATE, AMAX, false, 0, 3>), grid, block, lds_bytes, st, p);
+    return launch_status("linear_f32x3");
+}
+
+static int split_args_ok(const char* what, const float* x, const unsigned short* w3, const float* scale, const float* bias,
+                         const float* residual, const float* gate, const float* y, int M, int K, int N) {
+    if (!x || !w3 || M <= 0 || K <= 0 || N <= 0) { set_error("%s: bad arguments", what); return ICAP_ERR_ARG; }
+    if (K % 8 || N % 4) { set_error("%s: K=%d must be a multiple of 8 and N=%d of 4", what, K, N); return ICAP_ERR_ALIGN; }
+    if (!aligned16(x) || !aligned16(w3) || (y && !aligned16(y)) || (scale && !aligned16(scale)) || (bias && !aligned16(bias)) ||
+        (residual && !aligned16(residual)) || (gate && !aligned16(gate)) || (((size_t)N * K * 2) & 15)) {
+        set_error("%s: pointers (and every weight plane) must be 16-byte aligned", what);
+        return ICAP_ERR_ALIGN;
+    }
+    if ((long long)M * N > (1LL << 40) || (long long)((M + 63) / 64) * ((N + 63) / 64) > 0x7fffffffLL) { set_error("%s: problem too large", what); return ICAP_ERR_LIMIT; }
+    return ICAP_OK;
+}
+
+// cfg: -1 = choose by shape, 0 = 128x128, 1 = 64x128, 2 = 64x64 tiles
+int linear_f32x3_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
+                     const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, hipStream_t st) {
+    if (!y || (gate && hw <= 0)) { set_error("linear_f32x3: bad arguments"); return ICAP_ERR_ARG; }
+    const int rc = split_args_ok("linear_f32x3", x, w3, scale, bias, residual, gate, y, M, K, N);
+    if (rc != ICAP_OK) return rc;
+    GemmBf16Params p{x, w3, scale, bias, residual, gate, y, M, N, K, gate ? hw : 1, act, 0, nullptr, nullptr};
+    if (cfg < 0) {
+        const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+        cfg = t128 >= 192 ? 0 : ((long long)((M + 63) / 64) * ((N + 127) / 128) >= 192 ? 1 : 2);
+    }
+    switch (cfg) {
+        case 0: return gate ? gb16_split_launch<128, 128, true, false>(p, st) : gb16_split_launch<128, 128, false, false>(p, st);
+        case 1: return gate ? gb16_split_launch<64, 128, true, false>(p, st) : gb16_split_launch<64, 128, false, false>(p, st);
+        case 2: return gate ? gb16_split_launch<64, 64, true, false>(p, st) : gb16_split_launch<64, 64, false, false>(p, st);
+        default: set_error("linear_f32x3: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
+    }
+}
+
+// vocabulary projection with arg-max partials per 128-column tile (linear_bf16_argmax_parts(N) per row)
+int linear_f32x3_argmax_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, float* y, float* part_val,
+                            int* part_idx, int M, int K, int N, hipStream_t st) {
+    if (!part_val || !part_idx) { set_error("linear_f32x3_argmax: null partial buffers"); return ICAP_ERR_ARG; }
+    const int rc = split_args_ok("linear_f32x3_argmax", x, w3, scale, bias, nullptr, nullptr, y, M, K, N);
+    if (rc != ICAP_OK) return rc;
+    GemmBf16Params p{x, w3, scale, bias, nullptr, nullptr, y, M, N, K, 1, ACT_NONE, 0, part_val, part_idx};
+    return M > 64 ? gb16_split_launch<128, 128, false, true>(p, st) : gb16_split_launch<64, 128, false, true>(p, st);
+}
+
+// fp32 [n] -> three bf16 planes [3][n]: hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid); n a multiple of 2
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, long long n2) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) {
+        float a = src[2 * i], b = src[2 * i + 1];
+        const unsigned h = pack_bf16(a, b);
+        a -= __uint_as_float(h << 16); b -= __uint_as_float(h & 0xffff0000u);
+        const unsigned m = pack_bf16(a, b);
+        a -= __uint_as_float(m << 16); b -= __uint_as_float(m & 0xffff0000u);
+        dst[i] = h;
+        dst[n2 + i] = m;
+        dst[2 * n2 + i] = pack_bf16(a, b);
+    }
+}
+
+int split3_f32(const float* src, unsigned short* dst, long long n, hipStream_t st) {
+    if (!src || !dst || n <= 0 || (n & 1)) { set_error("split3: bad arguments (n must be even)"); return ICAP_ERR_ARG; }
+    long long blocks = (n / 2 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, reinterpret_cast<unsigned*>(dst), n / 2);
+    return launch_status("split3");
 }
 
 // fp32 -> bf16 (round to nearest even), n a multiple of 2

@@ -335,3 +335,50 @@ def test_linear_bf16(M, K, N, act, use_res, use_gate, cfg):
     exact = ref(xg.to(torch.bfloat16).float(), w.to(torch.bfloat16).float())
     close(got, exact, rtol=1e-4, atol=1e-4, what="linear_bf16 vs bf16-rounded operands")
     close(got, ref(xg, w), rtol=2e-2, atol=2e-2, what="linear_bf16 vs fp32 (bf16 tolerance: 2e-2)")
+
+
+@pytest.mark.parametrize("M,K,N,act,use_res,use_gate,cfg", [
+    (1024, 512, 6756, 0, False, False, -1), (300, 512, 6756, 0, False, False, 2), (1000, 112, 672, 2, False, False, 0),
+    (392, 672, 112, 0, True, True, 1), (98, 1152, 320, 0, False, True, -1), (7, 2048, 512, 1, True, False, -1),
+    (260, 40, 240, 2, False, False, 0), (200, 2048, 512, 0, True, False, 1)])
+def test_linear_f32x3_is_fp32_accurate(M, K, N, act, use_res, use_gate, cfg):
+    """Six bf16 products per multiply from exact three-way splits: the result must be as close to the float64 product as
+    an fp32 computation is (the tolerance is a small multiple of what the fp32 MFMA kernel itself leaves)."""
+    from image_captioning_amd import ops
+    d = dev()
+    hw = 49 if use_gate else 1
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    scale = torch.rand(N, generator=torch.Generator().manual_seed(4)) + 0.5
+    res = rnd(M, N, seed=5) if use_res else None
+    gate = torch.rand(M // hw, K, generator=torch.Generator().manual_seed(6)) if use_gate else None
+    xg = x * gate.repeat_interleave(hw, 0) if use_gate else x
+    w3 = ops.split3(w.to(d))
+    planes = w3.float().cpu()
+    assert torch.equal(planes[0], w.to(torch.bfloat16).float())
+    assert torch.equal(planes.double().sum(0).float(), w) or (planes.double().sum(0) - w.double()).abs().max() <= 2.0 ** -24 * w.abs().max()
+    got = ops.linear_f32x3(x.to(d), w3, b.to(d), scale.to(d), act=act, residual=res.to(d) if use_res else None,
+                           gate=gate.to(d) if use_gate else None, hw=hw, cfg=cfg).cpu().double()
+    ref = (xg.double() @ w.double().t()) * scale.double() + b.double()
+    if use_res:
+        ref = ref + res.double()
+    ref = act_ref(ref, act)
+    f32 = ops.linear(xg.to(d), w.to(d), b.to(d), scale.to(d), act=act, residual=res.to(d) if use_res else None).cpu().double()
+    err, err32 = (got - ref).abs().max().item(), (f32 - ref).abs().max().item()
+    assert err <= max(4 * err32, 2e-6 * ref.abs().max().item()), (err, err32)
+
+
+@pytest.mark.parametrize("M,K,N", [(1024, 512, 6756), (70, 512, 84), (256, 2048, 6756)])
+def test_linear_f32x3_argmax(M, K, N):
+    from image_captioning_amd import ops
+    d = dev()
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = x.double() @ w.double().t() + b.double()
+    pv, pi, y = ops.linear_f32x3_argmax(x.to(d), ops.split3(w.to(d)), b.to(d), want_logits=True)
+    assert (y.cpu().double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+    ids = torch.full((M, 1), -1, dtype=torch.int64, device=d)
+    ops.next_token(pv, pi, ids, 0)
+    top2 = torch.topk(ref, 2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert torch.equal(ids[:, 0].cpu()[clear], ref.argmax(1)[clear])
+    pv2, pi2, none = ops.linear_f32x3_argmax(x.to(d), ops.split3(w.to(d)), b.to(d))
+    assert none is None and torch.equal(pv2, pv) and torch.equal(pi2, pi)

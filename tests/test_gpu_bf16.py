@@ -43,6 +43,68 @@ def test_bf16_mode_tracks_the_fp32_path(bf16_mode):
     assert torch.equal(i0[decided, 0], i1[decided, 0])
 
 
+BF16_FEATURE_TOL = 1e-2      # of the largest feature magnitude, against the fp32 CPU oracle
+BF16_LOGIT_TOL = 2e-2        # of the largest logit magnitude
+
+
+@pytest.mark.parametrize("cnn_type", ["resnet18", "vgg16"])
+def test_bf16_dense_encoders_against_the_cpu_oracle(bf16_mode, cnn_type):
+    """ResNet-18 / VGG-16 with bf16 products and bf16 activations between layers, against the fp32 CPU restatement of the
+    encoder (not against this library's own fp32 path): features within the stated bf16 tolerance."""
+    ops = bf16_mode
+    from image_captioning_amd import seq2seqbasic as s2s
+    from image_captioning_amd.preprocess import to_model_input
+    from image_captioning_amd.synthetic import seeded_state_dict, synthetic_images
+    from oracle import backbones_ref as BR
+    from tests import helpers as H
+    enc = s2s.EncoderCNN(256, cnn_type)
+    enc.load_state_dict(seeded_state_dict(enc, seed=41))
+    enc.eval()
+    sd = {"encoder." + k: v for k, v in H.cpu_sd(enc).items()}
+    imgs = torch.cat([to_model_input(H.load("food_test_u8")["images"])[:3], synthetic_images(1)])
+    want = BR.seq2seq_encoder(sd, imgs, cnn_type)
+    ops.set_compute_dtype("bf16")
+    got = enc.to(D)(imgs.to(D)).cpu()
+    err = float((got - want).abs().max())
+    assert 0 < err <= BF16_FEATURE_TOL * float(want.abs().max()), (err, float(want.abs().max()))
+
+
+def test_bf16_captioner_against_the_cpu_oracle(bf16_mode):
+    """EfficientNet-B0 + word-level transformer in bf16 mode on the food photos against the CPU oracle: features and
+    first-step logits within the stated tolerance, greedy ids equal wherever the ORACLE's top-2 gap exceeds twice the
+    observed logit error (a bf16 logit error can legitimately flip closer calls)."""
+    ops = bf16_mode
+    from image_captioning_amd import transformer_word_level as twl
+    from image_captioning_amd.preprocess import to_model_input
+    from image_captioning_amd.synthetic import seeded_state_dict
+    from oracle import backbones_ref as BR, torch_ref as R
+    from tests import helpers as H
+    V, steps = 6756, 6
+    model = twl.build_model(V)
+    model.load_state_dict(seeded_state_dict(model, seed=5))
+    model.eval()
+    sd = H.cpu_sd(model)
+    imgs = to_model_input(H.load("food_test_u8")["images"])[:4]
+    with torch.no_grad():
+        f_ref = BR.cnn_model(sd, imgs)
+        runs = [R.tfm_greedy(sd, f, 8, 8, steps, 2, 3, False) for f in f_ref]
+    ops.set_compute_dtype("bf16")
+    model = model.to(D)
+    feats = model.cnn_model(imgs.to(D))
+    ids, logits = model.greedy_ids_from_features(feats, steps, want_logits=True, lockstep=0)     # the batched GEMM path (bf16 GEMMs)
+    ferr = float((feats.cpu() - f_ref).abs().max())
+    assert 0 < ferr <= BF16_FEATURE_TOL * float(f_ref.abs().max())
+    for r, (want_ids, want_logits) in enumerate(runs):
+        lerr = float((logits[0, r].cpu() - want_logits[0]).abs().max())
+        assert lerr <= BF16_LOGIT_TOL * float(want_logits[0].abs().max()), (r, lerr)
+        top2 = torch.topk(want_logits, 2, dim=1).values
+        gaps = (top2[:, 0] - top2[:, 1]).tolist()
+        for t in range(steps):
+            if gaps[t] <= 2 * max(lerr, 1e-6) * 4:       # later steps accumulate nothing (no recurrence), but keep a margin
+                break
+            assert int(ids[r, t]) == want_ids[t], (r, t, gaps[t], lerr)
+
+
 def test_compute_dtype_switch_and_fallback_shapes(bf16_mode):
     ops = bf16_mode
     with pytest.raises(ops.IcapError):

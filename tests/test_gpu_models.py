@@ -129,6 +129,22 @@ def test_seq2seq_encoder(cnn_type):
     close(enc.to(dev())(imgs.to(dev())), want, f"EncoderCNN {cnn_type}", atol=1e-3 * float(want.abs().max()))
 
 
+def test_resnet18_encoder_at_256_pixels():
+    """seq2seqtest.py:178 resizes to 256 x 256: the adaptive average pool makes any size legal (stage sizes 64 / 32 / 16 / 8)."""
+    from image_captioning_amd import seq2seqbasic as s2s
+    from image_captioning_amd.preprocess import resize_normalize
+    from image_captioning_amd.synthetic import seeded_state_dict
+    from oracle import backbones_ref as BR
+    enc = s2s.EncoderCNN(256, "resnet18")
+    enc.load_state_dict(seeded_state_dict(enc, seed=41))
+    enc.eval()
+    sd = {"encoder." + k: v for k, v in H.cpu_sd(enc).items()}
+    imgs = resize_normalize(H.load("food_test_u8")["images"][:3], size=256).cpu()      # the food photos again, at 256 x 256
+    assert imgs.shape == (3, 3, 256, 256)
+    want = BR.seq2seq_encoder(sd, imgs, "resnet18")
+    close(enc.to(dev())(imgs.to(dev())), want, "EncoderCNN resnet18 @256", atol=1e-3 * float(want.abs().max()))
+
+
 def test_efficientnet_cnn_model():
     from image_captioning_amd.backbones import get_cnn_model
     from image_captioning_amd.synthetic import seeded_state_dict, synthetic_images

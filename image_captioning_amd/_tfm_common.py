@@ -306,6 +306,9 @@ class ImageCaptioningModelBase(nn.Module):
         if bf16 and "fc1_w16" not in wd:
             wd["fc1_w16"], wd["out_w16"] = ops.to_bf16(wd["fc1_w"]), ops.to_bf16(wd["out_w4"])
         V = wd["out_w"].shape[0]
+        x3 = ops.compute_dtype() == "f32x3" and wd["fc1_w"].shape[1] % 8 == 0 and B >= 256
+        if x3 and "out_w3" not in wd:
+            wd["out_w3"] = ops.split3(wd["out_w4"])
         for t in range(max_len):
             last = t + 1 == max_len
             if bf16:
@@ -314,6 +317,14 @@ class ImageCaptioningModelBase(nn.Module):
                 f = ops.linear(h, wd["fc2_w"], wd["fc2_b"], residual=x)
                 x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
                 pv, pi, logits = ops.linear_bf16_argmax(x2, wd["out_w16"], wd["out_b4"], want_logits=want_logits)
+                x = ops.next_token(pv, pi, ids, t, None if last else wd["emb"], None if last else ca,
+                                   None if last else wd["ln2_g"], None if last else wd["ln2_b"])
+            elif x3:
+                # fp32-accurate products on the bf16 matrix cores for the GEMMs they speed up (ops.linear_x3_auto decides)
+                h = ops.linear_x3_auto(x, wd["fc1_w"], wd, "fc1_w3", wd["fc1_b"], act=ops.ACT_RELU)
+                f = ops.linear_x3_auto(h, wd["fc2_w"], wd, "fc2_w3", wd["fc2_b"], residual=x)
+                x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
+                pv, pi, logits = ops.linear_f32x3_argmax(x2, wd["out_w3"], wd["out_b4"], want_logits=want_logits)
                 x = ops.next_token(pv, pi, ids, t, None if last else wd["emb"], None if last else ca,
                                    None if last else wd["ln2_g"], None if last else wd["ln2_b"])
             else:

@@ -56,8 +56,10 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // by a few units of fp32 rounding, at 6/16 of the fp32 MFMA's cost per multiply-add (v_mfma_f32_32x32x2_f32 retires
 // 64 flop per cycle and SIMD, v_mfma_f32_32x32x16_bf16 1024).  x is split while it is staged (three LDS planes), w points
 // to three pre-split planes [3][N][K].
+// Its three operand planes are single-buffered in LDS (60 KB for a 128 x 128 x 32 tile) so that TWO workgroups share a CU:
+// one workgroup's staging phase (global-load wait, the split arithmetic, LDS stores) runs under the other's MFMA phase.
 template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, int CONV = 0, int SPLIT = 1>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) {
+__global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(const GemmBf16Params p) {
     static_assert(!(CONV && (GATE || AMAX)) && !(CONV == 2 && A16), "the convolution form has no gate / arg-max; its 4-channel form reads fp32");
     static_assert(SPLIT == 1 || (SPLIT == 3 && !A16 && CONV == 0), "split products: fp32 activations, linear form");
     constexpr int BK = GB16_BK, LDK = GB16_LDK;
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
     constexpr int BP = (BN + 63) / 64;             // staging passes over W: thread t -> row t/4 + 64 i, bf16 8 (t%4) ..
     constexpr int EP_LD = BN + 4;
     constexpr int EP_ROWS = BM < 64 ? BM : 64;
-    constexpr int STAGE_BYTES = SPLIT * 2 * (BM + BN) * LDK * 2;
+    constexpr int NBUF = SPLIT == 3 ? 1 : 2;        // LDS buffers per operand plane
+    constexpr int STAGE_BYTES = SPLIT * NBUF * (BM + BN) * LDK * 2;
     constexpr int EP_BYTES = EP_ROWS * EP_LD * 4;
     constexpr int SMEM_BYTES = STAGE_BYTES > EP_BYTES ? STAGE_BYTES : EP_BYTES;
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is built from 32x32 blocks");
@@ -75,9 +78,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
     __shared__ __attribute__((aligned(16))) unsigned char smem_static[SPLIT == 1 ? SMEM_BYTES : 16];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     unsigned char* smem = SPLIT == 1 ? smem_static : smem_dyn;
-    unsigned short* As = reinterpret_cast<unsigned short*>(smem);            // [SPLIT][2][BM][LDK]
-    unsigned short* Bs = As + SPLIT * 2 * BM * LDK;                          // [SPLIT][2][BN][LDK]
-    constexpr int APL = 2 * BM * LDK, BPL = 2 * BN * LDK;                    // elements per plane
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem);            // [SPLIT][NBUF][BM][LDK]
+    unsigned short* Bs = As + SPLIT * NBUF * BM * LDK;                       // [SPLIT][NBUF][BN][LDK]
+    constexpr int APL = NBUF * BM * LDK, BPL = NBUF * BN * LDK;              // elements per plane
     float* ep = reinterpret_cast<float*>(smem);                              // [EP_ROWS][EP_LD], used after the K loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,7 +91,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
 
     // staging coordinates
     const int a_k4 = (tid & 7) * 4, a_row = tid >> 3;
-    const int b_k8 = (tid & 3) * 8, b_row = tid >> 2;
+    // W staging: four lanes cover a row's 64 bytes.  An LDS store instruction is serviced in groups of 8 lanes and rows are 80
+    // bytes apart, so the two rows of a group must be 4 rows apart (4 x 20 dwords = 16 mod 32 banks) not to meet in a bank.
+    const int b_k8 = (tid & 3) * 8, b_q = tid >> 2, b_row = (b_q & 1) * 4 + ((b_q >> 1) & 3) + (b_q >> 3) * 8;
     const float* a_src[AP];
     const float* g_src[GATE ? AP : 1];
     bool a_ok[AP];
@@ -143,9 +148,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
         b_src[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K;
     }
 
-    // staging register sets: the split form keeps two K slices in flight (its workgroup is alone on the CU, so a slice
-    // needs more than one step of MFMAs to arrive), the others one
-    constexpr int NSET = SPLIT == 3 ? 2 : 1;
+    constexpr int NSET = 1;                          // staging register sets (K slices in flight)
     float4 ra[NSET][AP], rg[NSET][GATE ? AP : 1];
     uint4 rb[NSET][SPLIT][BP];
     uint4 ra16[A16 ? AP16 : 1];
@@ -304,26 +307,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBf16Params p) 
 
     const int nk = (p.K + BK - 1) / BK;
     using T0 = std::integral_constant<int, 0>;
-    using T1 = std::integral_constant<int, NSET - 1>;
     gload(0, T0{});
     lds_store(0, T0{});
-    if constexpr (NSET == 2) {
-        // slice t in LDS buffer t & 1, slice t + 1 in register set (t + 1) & 1, slice t + 2 fetched during step t
-        if (nk > 1) gload(1, T1{});
-        __syncthreads();
-        for (int t = 0; t < nk; t += 2) {
-            if (t + 2 < nk) gload(t + 2, T0{});
+    if constexpr (NBUF == 1) {
+        // one LDS buffer: [wait for slice t's registers, split, store] [barrier] [fetch slice t+1] [MFMAs] [barrier]; the
+        // CU's other workgroup fills the gaps
+        for (int t = 0; t < nk; ++t) {
+            if (t > 0) lds_store(0, T0{});
+            __syncthreads();
+            if (t + 1 < nk) gload(t + 1, T0{});
             __builtin_amdgcn_sched_barrier(0);
             compute(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < nk) lds_store(1, T1{});
-            __syncthreads();
-            if (t + 1 >= nk) break;
-            if (t + 3 < nk) gload(t + 3, T1{});
-            __builtin_amdgcn_sched_barrier(0);
-            compute(1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < nk) lds_store(0, T0{});
             __syncthreads();
         }
     } else {
@@ -551,11 +546,11 @@ int linear_bf16_argmax_f32(const float* x, const unsigned short* w, const float*
 }
 
 // ---------------------------------------------------------------- fp32-accurate linear layers on split bf16 products
-// w3: three bf16 planes [3][N][K] made by split3_f32 from the fp32 weights.  Dynamic LDS: the three operand planes of a
-// double-buffered 128 x 128 x 32 tile take 120 KB, so one workgroup owns a CU.
+// w3: three bf16 planes [3][N][K] made by split3_f32 from the fp32 weights.  Dynamic LDS: the three single-buffered
+// operand planes of a 128 x 128 x 32 tile take 60 KB, two workgroups per CU.
 template <int BM, int BN>
 constexpr int gb16_split_smem() {
-    constexpr int stage = 3 * 2 * (BM + BN) * GB16_LDK * 2, ep = (BM < 64 ? BM : 64) * (BN + 4) * 4;
+    constexpr int stage = 3 * (BM + BN) * GB16_LDK * 2, ep = (BM < 64 ? BM : 64) * (BN + 4) * 4;
     return stage > ep ? stage : ep;
 }
 
@@ -593,7 +588,8 @@ int linear_f32x3_f32(const float* x, const unsigned short* w3, const float* scal
     GemmBf16Params p{x, w3, scale, bias, residual, gate, y, M, N, K, gate ? hw : 1, act, 0, nullptr, nullptr};
     if (cfg < 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-        cfg = t128 >= 192 ? 0 : ((long long)((M + 63) / 64) * ((N + 127) / 128) >= 192 ? 1 : 2);
+        const int waste = (N + 127) / 128 * 128 - N;            // columns of the last 128-wide tile that are padding
+        cfg = (t128 >= 192 && waste * 4 <= N) ? 0 : ((long long)((M + 63) / 64) * ((N + 127) / 128) >= 192 && waste * 4 <= N ? 1 : 2);
     }
     switch (cfg) {
         case 0: return gate ? gb16_split_launch<128, 128, true, false>(p, st) : gb16_split_launch<128, 128, false, false>(p, st);

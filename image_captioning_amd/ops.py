@@ -38,11 +38,14 @@ COMPUTE_DTYPE = "f32"
 
 
 def set_compute_dtype(name: str) -> None:
-    """"f32" (default): every product in fp32.  "bf16": the 1x1 convolutions of the EfficientNet encoder and the wide
+    """"f32" (default): every product in fp32 on the fp32 matrix-core instruction.  "f32x3": the MFMA-bound Linear / 1x1
+    convolution layers compute fp32-ACCURATE products on the bf16 matrix cores (exact three-way bf16 splits of both
+    operands, six products per multiply, fp32 accumulation: linear_f32x3) - same results to a few fp32 roundings, the
+    bf16 instruction's 16x flop rate divided by six; layers it does not speed up stay on the fp32 kernel.  "bf16": the 1x1 convolutions of the EfficientNet encoder and the wide
     decoder GEMMs (fc1, vocabulary projection) of the batched greedy path multiply bf16-rounded operands on the bf16
     matrix cores and accumulate in fp32; every tensor in memory stays fp32."""
     global COMPUTE_DTYPE
-    if name not in ("f32", "bf16"):
+    if name not in ("f32", "f32x3", "bf16"):
         raise IcapError(f"set_compute_dtype: unknown dtype {name!r}")
     COMPUTE_DTYPE = name
 
@@ -99,6 +102,67 @@ def step_cached(kind: str, src: torch.Tensor, make):
     return hit[1]
 
 
+# "f32x3" mode: which kernel runs a [M, K] x [N, K] layer.  Without tuning: the split kernel when the contraction is long
+# enough for the matrix cores to be the bound (measured cross-over), the fp32 kernel otherwise.  With AUTOTUNE on, the
+# first call of a shape times the fp32 kernel and the split kernel's tile configurations and remembers the fastest.
+X3_MIN_K = 160
+X3_MIN_TILES = 128
+_x3_choice: dict = {}
+_X3_FP32 = -2
+
+
+def _x3_pick(M, K, Nn, run_fp32, run_split):
+    key = (M, K, Nn)
+    c = _x3_choice.get(key)
+    if c is not None:
+        return c
+    if K % 8 or Nn % 4:
+        return _X3_FP32
+    if not AUTOTUNE:
+        tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
+        return -1 if (K >= X3_MIN_K and tiles >= X3_MIN_TILES) else _X3_FP32
+    best, best_ms = _X3_FP32, None
+    for cand in (_X3_FP32, 0, 1, 2):
+        fn = run_fp32 if cand == _X3_FP32 else (lambda c=cand: run_split(c))
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if best_ms is None or ms < best_ms:
+            best, best_ms = cand, ms
+    _x3_choice[key] = best
+    return best
+
+
+def linear_x3_auto(x, w, w3_cache: dict, key, bias=None, scale=None, act=ACT_NONE, residual=None, gate=None, hw=1):
+    """One Linear / 1x1-convolution layer in "f32x3" mode: the split-product kernel or the fp32 kernel, whichever
+    _x3_pick says; the weight's three bf16 planes are made on first use and kept in w3_cache[key]."""
+    M, K = x.shape
+    Nn = w.shape[0]
+
+    def w3():
+        t = w3_cache.get(key)
+        if t is None:
+            t = w3_cache[key] = split3(w.reshape(Nn, K).contiguous())
+        return t
+
+    def run_fp32():
+        xx = x.view(M // hw, hw, 1, K) if gate is not None else x.view(M, 1, 1, K)
+        rr = residual.view(xx.shape[0], xx.shape[1], 1, Nn) if residual is not None else None
+        return conv2d(xx, w.reshape(Nn, 1, 1, K), scale, bias, residual=rr, gate=gate, act=act).view(M, Nn)
+
+    def run_split(cfg):
+        return linear_f32x3(x, w3(), bias, scale, act=act, residual=residual, gate=gate, hw=hw, cfg=cfg)
+
+    c = _x3_pick(M, K, Nn, run_fp32, run_split)
+    return run_fp32() if c == _X3_FP32 else run_split(c)
+
+
 def pointwise_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None, gate=None, act=ACT_NONE):
     """1x1 convolution x [B,H,W,Cin] with w [Cout,1,1,Cin]: the fp32 implicit-GEMM kernel, or - in bf16 compute mode and
     for shapes the bf16 kernel accepts - icap_linear_bf16_f32 with a cached bf16 copy of the weight."""
@@ -113,6 +177,10 @@ def pointwise_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=N
         return y.view(B, H, W, Cout)
     if x.dtype != torch.float32:
         raise IcapError("pointwise_conv: a bf16 activation needs the bf16 kernel (Cin % 8 == 0, Cout % 4 == 0, bf16 mode)")
+    if COMPUTE_DTYPE == "f32x3":
+        y = linear_x3_auto(x.view(B * H * W, Cin), w, w16_cache, key + "_x3", bias, scale, act=act,
+                           residual=residual.view(B * H * W, Cout) if residual is not None else None, gate=gate, hw=H * W)
+        return y.view(B, H, W, Cout)
     return conv2d(x, w, scale, bias, residual=residual, gate=gate, act=act)
 
 

@@ -316,3 +316,48 @@ def test_pooling_of_bf16_activations(bf16_mode):
     a2 = ops.adaptive_avgpool2d(x, 7, 7)
     ref2 = F.adaptive_avg_pool2d(x.float().permute(0, 3, 1, 2), (7, 7)).permute(0, 2, 3, 1)
     torch.testing.assert_close(a2, ref2, rtol=1e-5, atol=1e-6)
+
+
+def test_f32x3_mode_matches_the_cpu_oracle_like_fp32(bf16_mode):
+    """"f32x3": fp32-accurate products on the bf16 matrix cores.  Unlike bf16 mode it must meet the FP32 bar: encoder
+    features and logits within rtol 1e-3 of the CPU oracle, greedy ids exact under the 1e-4 gap rule - with and without
+    the per-shape tuner choosing between the split kernel's configurations and the fp32 kernel."""
+    ops = bf16_mode
+    from image_captioning_amd import transformer_word_level as twl
+    from image_captioning_amd.preprocess import to_model_input
+    from image_captioning_amd.synthetic import seeded_state_dict, synthetic_images
+    from oracle import backbones_ref as BR, torch_ref as R
+    from tests import helpers as H
+    V, steps, n_or = 6756, 6, 4
+    model = twl.build_model(V)
+    model.load_state_dict(seeded_state_dict(model, seed=5))
+    model.eval()
+    sd = H.cpu_sd(model)
+    imgs = torch.cat([to_model_input(H.load("food_test_u8")["images"]), synthetic_images(24, seed=3)])     # 32 images
+    imgs = imgs.repeat(8, 1, 1, 1)                                                                           # 256: the GEMM path's split kernels engage
+    with torch.no_grad():
+        f_ref = BR.cnn_model(sd, imgs[:n_or])
+        runs = [R.tfm_greedy(sd, f, 8, 8, steps, 2, 3, False) for f in f_ref]
+    model = model.to(D)
+    x = imgs.to(D)
+    ops.set_compute_dtype("f32")
+    f32_feats = model.cnn_model(x).clone()
+    for tune in (False, True):
+        ops.set_compute_dtype("f32x3")
+        ops.set_autotune(tune)
+        try:
+            feats = model.cnn_model(x)
+            ids, logits = model.greedy_ids_from_features(feats, steps, want_logits=True)
+        finally:
+            ops.set_autotune(False)
+        assert not torch.equal(feats, f32_feats), "the split kernels did not run"
+        err = (feats[:n_or].cpu() - f_ref).abs()
+        assert float((err - (1e-3 * f_ref.abs() + 1e-3 * float(f_ref.abs().max()))).max()) <= 0
+        assert float((feats - f32_feats).abs().max()) <= 2e-5 * float(f32_feats.abs().max())      # a few fp32 roundings per layer
+        for r, (want_ids, want_logits) in enumerate(runs):
+            got = logits[:, r].cpu()
+            assert float(((got - want_logits).abs() - (1e-4 + 1e-3 * want_logits.abs())).max()) <= 0
+            top2 = torch.topk(want_logits, 2, dim=1).values
+            gaps = (top2[:, 0] - top2[:, 1]).unsqueeze(0).numpy()
+            H.assert_ids_match(ids[r:r + 1].cpu().numpy(), [want_ids], gaps, f"f32x3 image {r} tune={tune}")
+        assert torch.equal(ids[:32], ids[32:64])          # the tiled copies of an image decode alike

@@ -340,7 +340,8 @@ def test_linear_bf16(M, K, N, act, use_res, use_gate, cfg):
 @pytest.mark.parametrize("M,K,N,act,use_res,use_gate,cfg", [
     (1024, 512, 6756, 0, False, False, -1), (300, 512, 6756, 0, False, False, 2), (1000, 112, 672, 2, False, False, 0),
     (392, 672, 112, 0, True, True, 1), (98, 1152, 320, 0, False, True, -1), (7, 2048, 512, 1, True, False, -1),
-    (260, 40, 240, 2, False, False, 0), (200, 2048, 512, 0, True, False, 1)])
+    (260, 40, 240, 2, False, False, 0), (200, 2048, 512, 0, True, False, 1),
+    (300, 1000, 200, 1, True, False, 2), (130, 32, 132, 0, False, False, 0), (129, 24, 4, 3, False, False, 1)])
 def test_linear_f32x3_is_fp32_accurate(M, K, N, act, use_res, use_gate, cfg):
     """Six bf16 products per multiply from exact three-way splits: the result must be as close to the float64 product as
     an fp32 computation is (the tolerance is a small multiple of what the fp32 MFMA kernel itself leaves)."""

@@ -245,6 +245,13 @@ int icap_expand_dwconv_bf16_f32(const float* x, const float* w_exp, const float*
                              stride, pad_t, pad_l, Ho, Wo, 1 | (y_bf16 ? 2 : 0), (hipStream_t)stream);
 }
 
+int icap_expand_dwconv_f32x3_f32(const float* x, const float* w_exp, const float* exp_scale, const float* exp_bias, const float* w_dw,
+                                 const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int H, int W, int Cin,
+                                 int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+    return expand_dwconv_f32(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, y, partial, B, H, W, Cin, Cexp, KS, stride,
+                             pad_t, pad_l, Ho, Wo, 4, (hipStream_t)stream);
+}
+
 int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias, const float* w_dw,
                          const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int img_h, int img_w,
                          int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,

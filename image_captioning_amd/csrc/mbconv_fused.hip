@@ -36,13 +36,20 @@ constexpr int xd_waves() {
 // STEM: the first convolution is not a 1x1 expand but EfficientNet's 3x3 stride-2 stem on the 4-channel-padded image
 // (x [B][img_h][img_w][4], we [Cexp][3][3][4]): the GEMM's K axis is the 36-element patch, padded to 40 (ten taps, five per
 // lane half, the tenth zero), gathered straight from the image; H x W is then the stem's OUTPUT size.
-template <int CIN, int KS, int S, int TH, int TW, int SW, bool STEM = false, bool BF16 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS, S, TH, TW, STEM && BF16>()))) void expand_dw_kernel(
+// PROD: how the expand GEMM multiplies.  0: v_mfma_f32_32x32x2_f32.  1: operands rounded to bf16, v_mfma_f32_32x32x16_bf16.
+// 3: fp32-accurate on the bf16 instruction - both operands as exact three-way bf16 splits (hi, mid, lo), the six products
+// hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi per K block (the dropped three are <= 2^-24 of the product): for CIN = 24,
+// 12 bf16 MFMAs of 32 cycles instead of 12 fp32 MFMAs of 64.
+template <int CIN, int KS, int S, int TH, int TW, int SW, bool STEM = false, int PROD = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS, S, TH, TW, STEM && PROD == 1>()))) void expand_dw_kernel(
     const float* __restrict__ x, const float* __restrict__ we, const float* __restrict__ es, const float* __restrict__ eb,
     const float* __restrict__ wd, const float* __restrict__ dsc, const float* __restrict__ dbi, float* __restrict__ y,
     float* __restrict__ partial, int H, int W, int Cexp, int pad_t, int pad_l, int Ho, int Wo, int tiles_w, int cpg,
     int img_h, int img_w, int stem_pad_t, int stem_pad_l, int out16) {
     static_assert(!STEM || CIN == 40, "the stem patch is 36 values padded to 40");
+    static_assert(PROD == 0 || PROD == 1 || (PROD == 3 && !STEM), "split products: expanding blocks only");
+    constexpr bool BF16 = PROD != 0;       // operands go through packed bf16 registers
+    constexpr int NPL = PROD == 3 ? 3 : 1;  // bf16 planes per operand
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS, P = IH * IW;
     constexpr int MB = (P + 31) / 32;          // 32-pixel row blocks
     constexpr int NRB = (MB + 3) / 4;          // row blocks per wave
@@ -168,7 +175,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
             o[c] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     };
-    uint4 a16[BF16 ? NRB : 1][NCH], b16[NCH];
+    // residual of f after its packed bf16 heads o (exact in fp32): the next plane of a split is the head of this
+    auto residual8 = [&](float (&f)[KH2], const uint4 (&o)[NCH]) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned w[4] = {o[c].x, o[c].y, o[c].z, o[c].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 8 * c + 2 * j;
+                if (k < KH2) f[k] -= __uint_as_float(w[j] << 16);
+                if (k + 1 < KH2) f[k + 1] -= __uint_as_float(w[j] & 0xffff0000u);
+            }
+        }
+    };
+    auto pack_planes = [&](const float (&f)[KH2], uint4 (&o)[NPL][NCH]) {
+        pack8(f, o[0]);
+        if constexpr (NPL == 3) {
+            float r[KH2];
+#pragma unroll
+            for (int k = 0; k < KH2; ++k) r[k] = f[k];
+            residual8(r, o[0]);
+            pack8(r, o[1]);
+            residual8(r, o[1]);
+            pack8(r, o[2]);
+        }
+    };
+    uint4 a16[BF16 ? NRB : 1][NPL][NCH], b16[NPL][NCH];
     const int ch_begin = blockIdx.z * cpg;
     {
         float braw[KH2], s_;
@@ -176,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
         float4 wv, ws4;
         load_dw_params(ch_begin, wv, ws4);
         fold_b(bf, braw, s_);
-        if constexpr (BF16) pack8(bf, b16);
+        if constexpr (BF16) pack_planes(bf, b16);
         if (wrow < WROWS) Wl[ch_begin & 1][wrow][q] = fold_dw(wv, ws4);
     }
 
@@ -204,11 +236,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[e] = bi;
                     if constexpr (BF16) {
-                        if (ch == ch_begin) pack8(af[i], a16[i]);
+                        if (ch == ch_begin) pack_planes(af[i], a16[i]);
 #pragma unroll
-                        for (int c = 0; c < NCH; ++c)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xd_bf16x8, a16[i][c]),
-                                                                          __builtin_bit_cast(xd_bf16x8, b16[c]), acc, 0, 0, 0);
+                        for (int c = 0; c < NCH; ++c) {
+                            if constexpr (NPL == 3) {   // smallest terms first: (a plane, b plane) with plane sum <= 2
+                                constexpr int pa[5] = {2, 0, 1, 1, 0}, pb[5] = {0, 2, 1, 0, 1};
+#pragma unroll
+                                for (int t5 = 0; t5 < 5; ++t5)
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xd_bf16x8, a16[i][pa[t5]][c]),
+                                                                                  __builtin_bit_cast(xd_bf16x8, b16[pb[t5]][c]), acc, 0, 0, 0);
+                            }
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xd_bf16x8, a16[i][0][c]),
+                                                                          __builtin_bit_cast(xd_bf16x8, b16[0][c]), acc, 0, 0, 0);
+                        }
                     } else {
 #pragma unroll
                         for (int s = 0; s < KH2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[s], acc, 0, 0, 0);
@@ -314,7 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
             *reinterpret_cast<float4*>(partial + ((size_t)b * gridDim.x + tile) * Cexp + c) = t;
         }
         fold_b(bf, bfn, scn);
-        if constexpr (BF16) pack8(bf, b16);
+        if constexpr (BF16) pack_planes(bf, b16);
         bi = bin;
     }
 }
@@ -345,8 +385,10 @@ int expand_dwconv_f32(const float* x, const float* we, const float* es, const fl
         set_error("expand_dwconv: bad arguments");
         return ICAP_ERR_ARG;
     }
-    const int out16 = (bf16 >> 1) & 1;     // bf16: bit 0 = bf16 products, bit 1 = bf16 output tensor
+    const int out16 = (bf16 >> 1) & 1;     // bf16: bit 0 = bf16 products, bit 1 = bf16 output tensor, bit 2 = fp32-accurate split products
+    const int x3 = (bf16 >> 2) & 1;
     bf16 &= 1;
+    if (x3 && (bf16 || out16)) { set_error("expand_dwconv: split products give an fp32 result"); return ICAP_ERR_ARG; }
     const XdCfg* c = xd_find(Cin, KS, stride);
     if (!c || Cexp <= 0 || Cexp % 4) {
         set_error("expand_dwconv: no fused kernel for Cin=%d, %dx%d stride %d, Cexp=%d", Cin, KS, KS, stride, Cexp);
@@ -374,7 +416,9 @@ int expand_dwconv_f32(const float* x, const float* we, const float* es, const fl
     const dim3 grid(ntiles, B, zg), block(256);
 #define ICAP_XD(CIN_, KS_, S_, TH_, TW_, SW_)                                                                                     \
     do {                                                                                                                          \
-        if (bf16) hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_, false, true>), grid, block, 0, st, x, we, es, \
+        if (x3) hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_, false, 3>), grid, block, 0, st, x, we, es,     \
+                                   eb, wd, ds, db, y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0, 0);     \
+        else if (bf16) hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_, false, 1>), grid, block, 0, st, x, we, es, \
                                      eb, wd, ds, db, y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0, out16); \
         else hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_>), grid, block, 0, st, x, we, es, eb, wd, ds, db,  \
                                 y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0, out16);                   \
@@ -422,7 +466,7 @@ int stem_dwconv_f32(const float* x, const float* ws, const float* ss, const floa
     const int ntiles = ((Ho + STEM_TH - 1) / STEM_TH) * tiles_w;
     const int nchunks = (C + XD_CC - 1) / XD_CC;
     const dim3 grid(ntiles, B, 1), block(256);
-    if (bf16) hipLaunchKernelGGL((expand_dw_kernel<40, 3, 1, STEM_TH, STEM_TW, 7, true, true>), grid, block, 0, st, x, ws, ss, sb, wd, ds,
+    if (bf16) hipLaunchKernelGGL((expand_dw_kernel<40, 3, 1, STEM_TH, STEM_TW, 7, true, 1>), grid, block, 0, st, x, ws, ss, sb, wd, ds,
                                  db, y, partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l, out16);
     else hipLaunchKernelGGL((expand_dw_kernel<40, 3, 1, STEM_TH, STEM_TW, 7, true>), grid, block, 0, st, x, ws, ss, sb, wd, ds, db, y,
                             partial, Hs, Ws, C, pad_t, pad_l, Ho, Wo, tiles_w, nchunks, img_h, img_w, stem_pad_t, stem_pad_l, out16);

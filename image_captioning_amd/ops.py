@@ -442,6 +442,8 @@ def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, k
     tail = (_ck(partial, "partial"), B, H, W, Cin, Cexp, ks, stride, pt, pl, Ho, Wo, _stream())
     if bf16:
         N.check(lib.icap_expand_dwconv_bf16_f32(*head, _ck(y, "y", ydt), int(out_bf16), *tail), "expand_dwconv2d")
+    elif COMPUTE_DTYPE == "f32x3":
+        N.check(lib.icap_expand_dwconv_f32x3_f32(*head, _ck(y, "y"), *tail), "expand_dwconv2d")
     else:
         N.check(lib.icap_expand_dwconv_f32(*head, _ck(y, "y"), *tail), "expand_dwconv2d")
     span.done()

@@ -118,6 +118,14 @@ int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_
                          int Ho, int Wo, void* stream);
 int icap_stem_dwconv_chunks(int Ho, int Wo, int C);
 
+/* icap_expand_dwconv_f32 with its expand GEMM as fp32-ACCURATE products on the bf16 matrix cores (exact three-way bf16
+ * splits of both operands in registers, six products per multiply, fp32 accumulation - see icap_linear_f32x3_f32):
+ * same arguments, same result to a few fp32 roundings, half the matrix-core cycles of the fp32 instruction. */
+int icap_expand_dwconv_f32x3_f32(const float* x, const float* w_exp, const float* exp_scale, const float* exp_bias,
+                                 const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial,
+                                 int B, int H, int W, int Cin, int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho,
+                                 int Wo, void* stream);
+
 /* The two fused kernels with bf16 products in their first (expand / stem) convolution - operands rounded to bf16 in
  * registers, fp32 accumulation on v_mfma_f32_32x32x16_bf16; the depthwise stage computes in fp32.  y is fp32
  * (y_bf16 = 0) or a bf16 tensor of the same shape (y_bf16 = 1, round to nearest even; the squeeze-excite partial sums

@@ -116,11 +116,21 @@ def test_dwconv_and_se(C, H, W, ks, s, pad):
 @pytest.mark.parametrize("Cin,Cexp,H,W,ks,s,pad", [(16, 96, 37, 41, 3, 2, (0, 1, 0, 1)), (24, 144, 28, 30, 3, 1, (1, 1, 1, 1)),
                                                     (24, 144, 29, 27, 5, 2, (1, 2, 1, 2)), (40, 240, 28, 17, 5, 1, (2, 2, 2, 2)),
                                                     (40, 240, 28, 28, 3, 2, (0, 1, 0, 1)), (16, 100, 16, 16, 3, 2, (0, 1, 0, 1))])
-def test_fused_expand_dwconv(Cin, Cexp, H, W, ks, s, pad):
+@pytest.mark.parametrize("mode", ["f32", "f32x3"])
+def test_fused_expand_dwconv(Cin, Cexp, H, W, ks, s, pad, mode):
     """1x1 expand + BN + swish + depthwise + BN + swish in one kernel == the two torch convolutions; sizes that do not
-    divide the kernel's tiles, TF-'same' asymmetric padding, a channel count that is not a multiple of the 32-wide chunk."""
+    divide the kernel's tiles, TF-'same' asymmetric padding, a channel count that is not a multiple of the 32-wide chunk.
+    Both with the fp32 matrix-core instruction and with split bf16 products (same fp32 tolerance)."""
     from image_captioning_amd import ops
     d = dev()
+    ops.set_compute_dtype(mode)
+    try:
+        _fused_expand_dwconv_case(ops, d, Cin, Cexp, H, W, ks, s, pad)
+    finally:
+        ops.set_compute_dtype("f32")
+
+
+def _fused_expand_dwconv_case(ops, d, Cin, Cexp, H, W, ks, s, pad):
     B = 3
     x = rnd(B, Cin, H, W, seed=1)
     we = rnd(Cexp, Cin, 1, 1, seed=2, scale=Cin ** -0.5)

@@ -233,8 +233,8 @@ def verify_caption(torch, ops, model, images, ids_timed, n_oracle=16):
 
 
 def verify_train(torch, ops, dev, rank, B, loss_tuned, seed_state):
-    """The training secondary's first step ran tuned tile configurations: the same step (same weights, inputs, dropout
-    seed) on the untuned configurations must give the same loss."""
+    """The training secondary's first step ran tuned tile configurations (and, in f32x3 mode, split-product GEMMs): the same
+    step (same weights, inputs, dropout seed) in plain fp32 on the untuned configurations must give the same loss."""
     from image_captioning_amd._bah_train import DropoutState
     with ops.untuned():
         _, step = build_train_step(torch, dev, rank, B)
@@ -317,6 +317,8 @@ CAPTION_DTYPES = {"f32": "f32",
 TRAIN_WORKLOAD = ("transformer_word_level_bahdnau: teacher-forced training step (EfficientNet-B0 train mode + encoder block + "
                   "Bahdanau LSTMCell decoder, compute_loss, backward, AdamW)")
 TRAIN_DTYPES = {"f32": "f32",
+                "f32x3": "f32 (fp32-accurate: forward GEMMs and input gradients of the large layers as six exact bf16 products per multiply "
+                         "from three-way operand splits, fp32 accumulate; weight gradients and every other kernel plain fp32)",
                 "bf16": "bf16 products in the forward GEMMs and input gradients / f32 accumulation, master weights, activations, "
                         "weight gradients and optimizer"}
 TRAIN_BF16_TOLERANCE = ("loss within 2e-2, gradients within 0.1 relative L2 (cosine > 0.99) of the f32 step "
@@ -352,12 +354,12 @@ def train_parallelism(model, world):
     return f"data-parallel x{world}, bucketed all-reduce of {sum(p.numel() for p in model.parameters()) * 4 / 1e6:.1f} MB of gradients"
 
 
-def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
-    note(rank, f"train secondary: building the model, batch {B}")
+def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256, dtype="f32"):
+    note(rank, f"train secondary: building the model, batch {B}, {dtype}")
     """The second half of the metric, measured after the contract's timed region on the same ranks: K training steps
     between barriers, max over ranks -> the "train" object of the JSON line."""
     from image_captioning_amd._bah_train import DropoutState
-    model, step = build_train_step(torch, dev, rank, B)
+    model, step = build_train_step(torch, dev, rank, B, dtype)
 
     def barrier():
         if world > 1:
@@ -386,26 +388,32 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res = {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": 3,
-           "images_per_step_per_gpu": B, "dtype": "f32", "scaling": "weak", "loss_last_step": float(loss),
+           "images_per_step_per_gpu": B, "dtype": TRAIN_DTYPES[dtype], "scaling": "weak", "loss_last_step": float(loss),
            "workload": TRAIN_WORKLOAD, "parallelism": train_parallelism(model, world)}
     res["verified"], res["verification"] = check["ok"], check                    # rank 0's own check is the one reported
+
+    def timed_as(kind, label):
+        step.trainer.dtype = kind
+        for _ in range(2):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        note(rank, f"train secondary, {label}: {steps} steps in {dt:.2f} s")
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return {"value": world * B * steps / dt, "unit": "imgs/s", "ms_per_step": dt / steps * 1e3, "dtype": TRAIN_DTYPES[kind],
+                "loss_last_step": float(last)}
+
+    if dtype == "f32x3":        # the same trainer on the fp32 matrix-core instruction only, for comparison
+        res["plain_f32"] = timed_as("f32", "plain fp32 products")
     # the same trainer with bf16 products (BASELINE configs[2] names bf16), same K steps between the same barriers
-    step.trainer.dtype = "bf16"
-    for _ in range(2):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    note(rank, f"train secondary, bf16 products: {steps} steps in {elapsed:.2f} s")
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    res["bf16"] = {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "dtype": TRAIN_DTYPES["bf16"],
-                   "loss_last_step": float(loss), "tolerance": TRAIN_BF16_TOLERANCE}
+    res["bf16"] = dict(timed_as("bf16", "bf16 products"), tolerance=TRAIN_BF16_TOLERANCE)
     # single process only: the step at the reference's loader batch (12), replayed from a HIP graph (Trainer(graph=True))
     if world == 1:
         try:
@@ -495,8 +503,6 @@ def main():
     from image_captioning_amd.synthetic import seeded_state_dict, synthetic_captions, synthetic_images
 
     train = args.mode == "train"
-    if train and args.dtype == "f32x3":
-        args.dtype = "f32"            # the split-product mode is an inference mode; training has f32 and bf16
     B = args.batch or (256 if train else 1024)
     # synthetic images: a small seeded pool tiled to the batch (content does not change the work)
     pool = synthetic_images(min(B, 32), seed=1234 + rank)
@@ -674,7 +680,8 @@ def main():
 
         def run():
             try:
-                return train_secondary(torch, dist, ops, dev, world, rank, max(1, min(args.steps, 10)), args.train_batch)
+                return train_secondary(torch, dist, ops, dev, world, rank, max(1, min(args.steps, 10)), args.train_batch,
+                                       "f32x3" if args.dtype == "f32x3" else "f32")
             except Exception as e:      # noqa: BLE001 - reported in the line
                 return {"error": f"{type(e).__name__}: {e}"[:300]}
 

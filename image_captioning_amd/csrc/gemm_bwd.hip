@@ -134,14 +134,197 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const GemmParams p) {
     }
 }
 
-// c[m][n] = (accumulate ? c[m][n] : 0) + sum_s part[s][m][n], fixed order
+// TN form with wave tiles of several MFMA blocks: the weight gradients whose result is tens to hundreds of rows and
+// columns (dW of the 1x1 convolutions from 56 x 56 down to 7 x 7, of the vocabulary projection and the LSTM gates).  Both
+// operands are k-major, staged [BK k][BM m] with 16-byte loads and stores and read back one float per lane; per K pair
+// a wave issues RM + RN LDS reads for RM x RN MFMAs (the 64 x 64 kernel above: 2 reads per MFMA), and two or three
+// workgroups share a CU.  The four waves are laid out WM x (4 / WM) over the tile, so that a result as narrow as 24 x 144
+// or 240 x 40 still fills whole 32 x 32 blocks along its long side.
+// v or zeros, by value: `ok ? a[i] : z` between two named objects becomes a select of ADDRESSES, which pins both to memory
+__device__ __forceinline__ float4 tn_keep(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+template <int BM, int BN, int WM, int BK>
+__global__ __launch_bounds__(256, 2) void gemm_tn_tile_kernel(const GemmParams p) {
+    constexpr int LDA = BM + 4, LDB = BN + 4, WN = 4 / WM;
+    constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);          // 32 x 32 blocks per wave along m and n
+    constexpr int PA = BK * BM / 1024, PB = BK * BN / 1024;          // float4 per thread and K step
+    static_assert(RM >= 1 && RN >= 1 && PA >= 1 && PB >= 1 && BK % 2 == 0, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_lo = blockIdx.z * p.k_per_split;
+    const int k_hi = min(p.K, k_lo + p.k_per_split);
+    const int nk = (k_hi - k_lo + BK - 1) / BK;
+    // The host guarantees lda, ldb, M, N multiples of 4, so a 16-byte group is inside the matrix or outside it as a whole.
+    // Every load is unconditional, from a clamped address, and zeroed afterwards: a branch around a load makes the
+    // compiler wait for each load before the next.
+    const float* a_src[PA];
+    const float* b_src[PB];
+    bool a_ok[PA], b_ok[PB];
+    int a_k[PA], b_k[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int idx = tid + 256 * i, col = m0 + (idx % (BM / 4)) * 4;
+        a_k[i] = idx / (BM / 4);
+        a_ok[i] = col < p.M;
+        a_src[i] = p.a + (a_ok[i] ? col : 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int idx = tid + 256 * i, col = n0 + (idx % (BN / 4)) * 4;
+        b_k[i] = idx / (BN / 4);
+        b_ok[i] = col < p.N;
+        b_src[i] = p.b + (b_ok[i] ? col : 0);
+    }
+    // two register sets: the loads of step t + 2 are issued while step t is being multiplied, so a load has two steps of
+    // matrix-core work (about 4 us) to arrive before it is written to LDS
+    float4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+    auto gload = [&](int t, float4 (&ra)[PA], float4 (&rb)[PB]) {
+        const int kb = k_lo + t * BK;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = kb + a_k[i];
+            ra[i] = *reinterpret_cast<const float4*>(a_src[i] + (size_t)(row < k_hi ? row : k_lo) * p.lda);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int row = kb + b_k[i];
+            rb[i] = *reinterpret_cast<const float4*>(b_src[i] + (size_t)(row < k_hi ? row : k_lo) * p.ldb);
+        }
+    };
+    // the values of step t go to LDS, zeroed where they lie outside the matrix or this split's rows (the select sits here,
+    // next to the store that has to wait for the load anyway, so the loads stay in flight during the previous step's MFMAs)
+    auto lds_store = [&](int buf, int t, const float4 (&ra)[PA], const float4 (&rb)[PB]) {
+        const int kb = k_lo + t * BK;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int idx = tid + 256 * i;
+            const bool ok = a_ok[i] && kb + a_k[i] < k_hi;
+            *reinterpret_cast<float4*>(&As[buf][(idx / (BM / 4)) * LDA + (idx % (BM / 4)) * 4]) = tn_keep(ok, ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int idx = tid + 256 * i;
+            const bool ok = b_ok[i] && kb + b_k[i] < k_hi;
+            *reinterpret_cast<float4*>(&Bs[buf][(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4]) = tn_keep(ok, rb[i]);
+        }
+    };
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    gload(0, ra0, rb0);
+    gload(1, ra1, rb1);
+    lds_store(0, 0, ra0, rb0);
+    gload(2, ra0, rb0);
+    __syncthreads();
+    int cur = 0;
+    // one step: multiply LDS buffer `cur` (step t), then write step t + 1 (in flight since step t - 1) to the other buffer
+    // and issue the loads of step t + 3 into the registers it frees
+    auto step = [&](int t, float4 (&ra)[PA], float4 (&rb)[PB]) {
+        const float* as = &As[cur][lh * LDA + wm * (BM / WM) + lr];
+        const float* bs = &Bs[cur][lh * LDB + wn * (BN / WN) + lr];
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float af[RM], bf[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) af[i] = as[2 * s * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) bf[j] = bs[2 * s * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        lds_store(cur ^ 1, t + 1, ra, rb);
+        __builtin_amdgcn_sched_barrier(0);      // keep the new loads behind the stores: hoisted, they land in a third register set
+                                                // and the copy back waits for them on the spot
+        gload(t + 3, ra, rb);       // unconditional: past the last step it re-reads row k_lo (valid memory) and the values are dropped
+        __syncthreads();
+        cur ^= 1;
+    };
+    // steps run in pairs (one per register set); with an odd count the last one multiplies a buffer of zeros
+    for (int t = 0; t < nk; t += 2) {
+        step(t, ra1, rb1);
+        step(t + 1, ra0, rb0);
+    }
+
+    float* c = p.c + (p.splits > 1 ? (size_t)blockIdx.z * p.M * p.N : 0);
+    const int ldc = p.splits > 1 ? p.N : p.ldc;
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int n = n0 + wn * (BN / WN) + 32 * j + lr;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / WM) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < p.M) c[(size_t)m * ldc + n] = acc[i][j][e];
+            }
+    }
+}
+
+struct TnTile {
+    int bm, bn;
+    void (*fn)(GemmParams);
+};
+// in order of preference when two tiles pad the result to the same area
+static const TnTile kTnTiles[] = {
+    {128, 128, gemm_tn_tile_kernel<128, 128, 2, 32>}, {256, 64, gemm_tn_tile_kernel<256, 64, 2, 16>},
+    {64, 256, gemm_tn_tile_kernel<64, 256, 2, 16>},   {128, 64, gemm_tn_tile_kernel<128, 64, 2, 32>},
+    {256, 32, gemm_tn_tile_kernel<256, 32, 4, 32>},   {32, 256, gemm_tn_tile_kernel<32, 256, 1, 32>},
+};
+
+// which tile the TN form uses for an M x N result: an index into kTnTiles (least padded area), or -1 for the 64 x 64
+// kernel (unaligned operands, results too small to fill a third of any tile)
+static int tn_tile(int M, int N, int lda = 0, int ldb = 0) {
+    if ((M | N | lda | ldb) & 3) return -1;
+    int best = -1;
+    long long best_area = 0;
+    for (int i = 0; i < (int)(sizeof(kTnTiles) / sizeof(kTnTiles[0])); ++i) {
+        const TnTile& t = kTnTiles[i];
+        const long long area = (long long)((M + t.bm - 1) / t.bm) * t.bm * ((N + t.bn - 1) / t.bn) * t.bn;
+        if (best < 0 || area < best_area) { best = i; best_area = area; }
+    }
+    return 3 * (long long)M * N >= best_area ? best : -1;
+}
+
+static int pick_splits_tile(int M, int N, int K, int bm, int bn) {
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    if (tiles >= 512 || K <= 256) return 1;
+    long long s = 512 / tiles > 0 ? 512 / tiles : 1;     // one round of two resident workgroups per CU: a second, partial round costs a whole pass
+    const long long max_s = K / 128 > 0 ? K / 128 : 1;   // at least 8 contraction steps per split
+    if (s > max_s) s = max_s;
+    if (s > 768) s = 768;
+    return (int)(s < 1 ? 1 : s);
+}
+
+// c[m][n] = (accumulate ? c[m][n] : 0) + sum_s part[s][m][n], fixed order; sixteen independent loads in flight per lane
+// (a plain loop chains one memory latency per split)
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N,
                                                                  float* __restrict__ c, int ldc, int accumulate) {
     const long long total = (long long)M * N;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i / N), n = (int)(i - (long long)m * N);
         float s = accumulate ? c[(size_t)m * ldc + n] : 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(size_t)k * total + i];
+        for (int k0 = 0; k0 < splits; k0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(k0 + u < splits ? k0 + u : k0) * total + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += k0 + u < splits ? v[u] : 0.f;
+        }
         c[(size_t)m * ldc + n] = s;
     }
 }
@@ -274,11 +457,14 @@ __global__ __launch_bounds__(256) void gemm_tn_finish_kernel(const float* __rest
 
 // The skinny form pays when the contraction is long and the result is at most a few blocks.
 static bool skinny_tn(int M, int N, int K) {
-    return K >= 32768 && (long long)((M + 31) / 32) * ((N + 31) / 32) <= 16 && (long long)M * N <= (1 << 20);
+    return K >= 32768 && (long long)((M + 31) / 32) * ((N + 31) / 32) <= 16 && (long long)M * N <= (1 << 20) &&
+           ((long long)((M + 31) / 32) * ((N + 31) / 32) <= 3 || tn_tile(M, N) < 0);
 }
 
-static int skinny_chunks(int K) {
-    int chunks = SK_CHUNKS;
+// A wave keeps 2 SK_U row pairs of loads in flight and rows are short (64-640 bytes), so bytes in flight come from
+// resident waves: 2048 workgroups (8 per CU) for tiles of one or two blocks, 1024 for the wider ones (registers).
+static int skinny_chunks(int K, int blocks) {
+    int chunks = blocks <= 2 ? 4 * SK_CHUNKS : 2 * SK_CHUNKS;
     while (chunks > 1 && K / (chunks * 4) < 4 * SK_U) chunks >>= 1;    // at least two batches of rows per wave
     return chunks;
 }
@@ -294,10 +480,15 @@ static void skinny_launch(const float* a, int lda, const float* b, int ldb, int 
 // floats of workspace gemm_bwd_f32 needs for this problem (0 when the contraction is not split and the result
 // is not accumulated onto C); sized for either operand layout
 long long gemm_bwd_ws_floats(int M, int N, int K, int accumulate) {
-    const int s = pick_splits(M, N, K);
+    int s = pick_splits(M, N, K);
+    const int tile = tn_tile(M, N);
+    if (tile >= 0) {
+        const int st = pick_splits_tile(M, N, K, kTnTiles[tile].bm, kTnTiles[tile].bn);
+        if (st > s) s = st;
+    }
     long long need = (s > 1 || accumulate) ? (long long)s * M * N : 0;
     if (skinny_tn(M, N, K)) {
-        const long long sk = (long long)skinny_chunks(K) * M * N;
+        const long long sk = (long long)skinny_chunks(K, 1) * M * N;
         if (sk > need) need = sk;
     }
     return need;
@@ -313,8 +504,9 @@ int gemm_bwd_f32(const float* a, int lda, int a_kmajor, const float* b, int ldb,
     if (!aligned16(a) || !aligned16(b)) { set_error("gemm_bwd: operands must be 16-byte aligned"); return ICAP_ERR_ALIGN; }
     if (a_kmajor && skinny_tn(M, N, K)) {
         if (!ws) { set_error("gemm_bwd: workspace required (gemm_bwd_ws_floats)"); return ICAP_ERR_ARG; }
-        const int chunks = skinny_chunks(K);
         const int mb = (M + 31) / 32, nb = (N + 31) / 32;
+        const int wide = mb >= nb ? mb : nb;
+        const int chunks = skinny_chunks(K, wide > 5 ? ((wide + 1) / 2 > 5 ? 4 : (wide + 1) / 2) : wide);
         // one of the two tile extents is a single block; the other covers up to five, the grid tiles the rest
         if (mb >= nb) {
             const int t = mb > 5 ? (mb + 1) / 2 > 5 ? 4 : (mb + 1) / 2 : mb;
@@ -337,7 +529,9 @@ int gemm_bwd_f32(const float* a, int lda, int a_kmajor, const float* b, int ldb,
         hipLaunchKernelGGL(gemm_tn_finish_kernel, dim3((M * N + 7) / 8), dim3(256), 0, st, ws, chunks, M, N, c, ldc, accumulate);
         return launch_status("gemm_bwd (skinny)");
     }
-    int splits = pick_splits(M, N, K);
+    const int tile = a_kmajor ? tn_tile(M, N, lda, ldb) : -1;
+    const int bm = tile >= 0 ? kTnTiles[tile].bm : GB_BM, bn = tile >= 0 ? kTnTiles[tile].bn : GB_BN;
+    int splits = tile >= 0 ? pick_splits_tile(M, N, K, bm, bn) : pick_splits(M, N, K);
     if (splits > 1 && !ws) { set_error("gemm_bwd: workspace required (gemm_bwd_ws_floats)"); return ICAP_ERR_ARG; }
     GemmParams p{a, b, c, M, N, K, lda, ldb, ldc, splits, 0};
     int kps = (K + splits - 1) / splits;
@@ -351,8 +545,9 @@ int gemm_bwd_f32(const float* a, int lda, int a_kmajor, const float* b, int ldb,
         p.c = ws;
         if (splits == 1) { p.splits = 2; }   // route the single partial through the workspace layout [1][M][N]
     }
-    const dim3 grid((N + GB_BN - 1) / GB_BN, (M + GB_BM - 1) / GB_BM, splits);
-    if (a_kmajor) hipLaunchKernelGGL(gemm_bwd_kernel<true>, grid, dim3(256), 0, st, p);
+    const dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm, splits);
+    if (tile >= 0) hipLaunchKernelGGL(kTnTiles[tile].fn, grid, dim3(256), 0, st, p);
+    else if (a_kmajor) hipLaunchKernelGGL(gemm_bwd_kernel<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(gemm_bwd_kernel<false>, grid, dim3(256), 0, st, p);
     if (!direct) {
         const long long total = (long long)M * N;

@@ -58,6 +58,9 @@ def compute_dtype() -> str:
 # TRAIN_DTYPE "bf16": every Linear / 1x1-convolution product of the step's forward pass and of its input gradients
 # (dX = dY W) multiplies bf16-rounded operands on the bf16 matrix cores with fp32 accumulation; parameters, activations,
 # gradients and optimizer state stay fp32 in memory, and the weight gradients (dW = dY^T X) are fp32 products.
+# TRAIN_DTYPE "f32x3": the same layers (forward and input gradients) as fp32-ACCURATE split products on the bf16 matrix
+# cores (linear_f32x3; the weight's three bf16 planes are made once per step), chosen per shape against the fp32 kernel
+# exactly as in the captioning path's "f32x3" mode; results equal the fp32 step's to a few fp32 roundings.
 # _step_cache: per-step copies derived from the weights (bf16 copies, transposed copies), built the first time a
 # weight is used in the step - the LSTM weights are used once per time step - and dropped when the step ends, before
 # the optimizer changes the weights.  An entry keeps its source tensor alive, so an address cannot be re-used by
@@ -75,7 +78,7 @@ class train_step:
     """Context of one training step's forward + backward: `with ops.train_step("bf16"): ...`."""
 
     def __init__(self, dtype: str = "f32"):
-        if dtype not in ("f32", "bf16"):
+        if dtype not in ("f32", "f32x3", "bf16"):
             raise IcapError(f"train_step: unknown dtype {dtype!r}")
         self.dtype = dtype
 
@@ -380,6 +383,22 @@ def linear(x, w, bias=None, scale=None, act=ACT_NONE, residual=None, out=None):
         # bf16 training step: same epilogue, bf16 products (the weight's bf16 copy is made once per step)
         w16 = step_cached("bf16", w, lambda: to_bf16(w))
         return linear_bf16(x, w16, bias, scale, act=act, residual=residual, out=out)
+    if TRAIN_DTYPE == "f32x3" and K % 8 == 0 and Nn % 4 == 0 and M >= TRAIN_BF16_MIN_ROWS:
+        def run_fp32(o=None):
+            return _linear_fp32(x, w, bias, scale, act, residual, torch.empty_like(out) if o is None else o)
+
+        def run_split(c, o=None):
+            return linear_f32x3(x, step_cached("split3", w, lambda: split3(w.contiguous())), bias, scale, act=act, residual=residual,
+                                out=torch.empty_like(out) if o is None else o, cfg=c)
+
+        c = _x3_pick(M, K, Nn, run_fp32, run_split)      # the tuner's trial runs write to scratch results (out may alias residual)
+        return run_fp32(out) if c == _X3_FP32 else run_split(c, out)
+    return _linear_fp32(x, w, bias, scale, act, residual, out)
+
+
+def _linear_fp32(x, w, bias, scale, act, residual, out):
+    M, K = x.shape
+    Nn = w.shape[0]
     span = _Span("linear", (M, K, Nn, residual is not None))
     N.check(_conv_entry((M, 1, 1, K, Nn, 1, 1, 1, 1, 1))(
         _ck(x, "x"), _ck(w, "w"), _ck(scale, "scale"), _ck(bias, "bias"), _ck(residual, "residual"), None,

@@ -404,8 +404,8 @@ class Trainer:
     def __init__(self, model, lr=1e-4, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, group=None, bucket_mb=16.0,
                  loss="compute_loss", overlap=None, dtype="f32", graph=False):
         import torch.distributed as dist
-        if dtype not in ("f32", "bf16"):
-            raise ValueError(f"Trainer: dtype must be 'f32' or 'bf16', not {dtype!r}")
+        if dtype not in ("f32", "f32x3", "bf16"):
+            raise ValueError(f"Trainer: dtype must be 'f32', 'f32x3' or 'bf16', not {dtype!r}")
         self.model = model
         self.graph = bool(graph)
         self._graph, self._graph_opt, self._eager_steps = None, None, 0

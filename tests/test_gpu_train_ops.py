@@ -23,7 +23,8 @@ def test_gemm_nn(M, K, N):
 
 
 @pytest.mark.parametrize("K,M,N", [(240, 6756, 512), (150528, 96, 16), (12, 512, 1024), (3136, 144, 24), (37, 20, 36), (2352, 1152, 192),
-                                   (40000, 24, 144), (33001, 36, 32), (50000, 240, 40), (65537, 17, 33), (40000, 144, 144)])
+                                   (40000, 24, 144), (33001, 36, 32), (50000, 240, 40), (65537, 17, 33), (40000, 144, 144),
+                                   (3001, 672, 112), (1000, 97, 49), (777, 130, 64), (2500, 480, 81), (515, 300, 1153)])
 def test_gemm_tn(K, M, N):
     from image_captioning_amd import train_ops as T
     a, b = rnd(K, M, seed=3), rnd(K, N, seed=4) * K ** -0.5
@@ -34,6 +35,15 @@ def test_gemm_tn(K, M, N):
     acc = base.to(D)
     T.gemm_tn(a.to(D), b.to(D), out=acc, accumulate=True)
     torch.testing.assert_close(acc.cpu(), base + want, rtol=1e-4, atol=2e-4)
+
+
+def test_gemm_tn_strided_rows():
+    """The wide-tile TN kernel on column slices of wider matrices, one of them with a row stride that is not a multiple of 4."""
+    from image_captioning_amd import train_ops as T
+    big_a, big_b = rnd(900, 403, seed=16), rnd(900, 260, seed=17)
+    a, b = big_a[:, 4:304], big_b[:, 20:220]
+    got = T.gemm_tn(big_a.to(D)[:, 4:304], big_b.to(D)[:, 20:220]).cpu()
+    torch.testing.assert_close(got, a.double().t().mm(b.double()).float(), rtol=1e-4, atol=2e-4)
 
 
 def test_gemm_strided_rows():

@@ -68,6 +68,7 @@ SIGNATURES = {
     "icap_dwconv_chunks": (_i, [_i] * 5),
     "icap_expand_dwconv_f32": (_i, [_p] * 9 + [_i] * 11 + [_p]),
     "icap_expand_dwconv_chunks": (_i, [_i] * 6),
+    "icap_expand_dwconv_whole_image": (_i, [_i] * 6),
     "icap_expand_dwconv_f32x3_f32": (_i, [_p] * 9 + [_i] * 11 + [_p]),
     "icap_stem_dwconv_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),
     "icap_stem_dwconv_chunks": (_i, [_i] * 3),

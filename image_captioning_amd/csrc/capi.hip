@@ -62,6 +62,7 @@ int dwconv_chunks(int, int, int, int, int);
 int expand_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                       float*, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int expand_dwconv_chunks(int, int, int, int, int, int);
+int expand_dwconv_whole_image(int, int, int, int, int, int);
 int stem_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                     float*, int, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int stem_dwconv_chunks(int, int, int);
@@ -272,6 +273,10 @@ int icap_stem_dwconv_chunks(int Ho, int Wo, int C) { return stem_dwconv_chunks(H
 
 int icap_expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int stride) {
     return expand_dwconv_chunks(Ho, Wo, Cin, Cexp, KS, stride);
+}
+
+int icap_expand_dwconv_whole_image(int H, int W, int Cin, int Cexp, int KS, int stride) {
+    return expand_dwconv_whole_image(H, W, Cin, Cexp, KS, stride);
 }
 
 int icap_se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr, const float* br, const float* we,

@@ -371,8 +371,15 @@ static const XdCfg* xd_find(int Cin, int KS, int stride) {
     return nullptr;
 }
 
+// mbconv_late.hip: the whole-image kernel of the 14 x 14 / 7 x 7 stride-1 blocks (fp32 only; one sum per image and channel)
+int expand_dwconv_whole_image(int H, int W, int Cin, int Cexp, int KS, int stride);
+int expand_dwconv_img_f32(const float* x, const float* we, const float* es, const float* eb, const float* wd, const float* ds,
+                          const float* db, float* y, float* pooled, int B, int H, int W, int Cin, int Cexp, int KS, int pad_t,
+                          int pad_l, hipStream_t st);
+
 // Number of per-image partial-sum chunks the fused kernel writes, or -1 when this layer shape has no fused kernel.
 int expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int stride) {
+    if (expand_dwconv_whole_image(Ho, Wo, Cin, Cexp, KS, stride)) return 1;
     const XdCfg* c = xd_find(Cin, KS, stride);
     if (!c || Ho <= 0 || Wo <= 0 || Cexp <= 0 || Cexp % 4) return -1;
     return ((Ho + c->th - 1) / c->th) * ((Wo + c->tw - 1) / c->tw);
@@ -389,6 +396,14 @@ int expand_dwconv_f32(const float* x, const float* we, const float* es, const fl
     const int x3 = (bf16 >> 2) & 1;
     bf16 &= 1;
     if (x3 && (bf16 || out16)) { set_error("expand_dwconv: split products give an fp32 result"); return ICAP_ERR_ARG; }
+    if (Ho == H && Wo == W && expand_dwconv_whole_image(H, W, Cin, Cexp, KS, stride)) {
+        if (bf16 || out16) { set_error("expand_dwconv: the whole-image kernel of the 14x14 / 7x7 blocks is fp32 only"); return ICAP_ERR_ARG; }
+        if (!aligned16(x) || !aligned16(we) || !aligned16(wd) || !aligned16(y) || (ds && !aligned16(ds)) || (db && !aligned16(db))) {
+            set_error("expand_dwconv: pointers must be 16-byte aligned");
+            return ICAP_ERR_ALIGN;
+        }
+        return expand_dwconv_img_f32(x, we, es, eb, wd, ds, db, y, partial, B, H, W, Cin, Cexp, KS, pad_t, pad_l, st);
+    }
     const XdCfg* c = xd_find(Cin, KS, stride);
     if (!c || Cexp <= 0 || Cexp % 4) {
         set_error("expand_dwconv: no fused kernel for Cin=%d, %dx%d stride %d, Cexp=%d", Cin, KS, KS, stride, Cexp);

@@ -431,8 +431,11 @@ def dwconv2d(x, w, scale=None, bias=None, *, ks, stride=1, pad=(0, 0, 0, 0), act
 def expand_dwconv_supported(H, W, Cin, Cexp, ks, stride, pad) -> bool:
     """True when the fused expand + depthwise kernel covers this layer shape."""
     pt, pb, pl, pr = pad
-    return N.load().icap_expand_dwconv_chunks(conv_out_size(H, ks, stride, pt, pb), conv_out_size(W, ks, stride, pl, pr),
-                                              Cin, Cexp, ks, stride) > 0
+    lib = N.load()
+    if lib.icap_expand_dwconv_whole_image(H, W, Cin, Cexp, ks, stride) and (COMPUTE_DTYPE == "bf16" or (pt, pl) != (ks // 2, ks // 2)):
+        return False         # the whole-image kernel of the 14x14 / 7x7 blocks: fp32 tensors, 'same' padding
+    return lib.icap_expand_dwconv_chunks(conv_out_size(H, ks, stride, pt, pb), conv_out_size(W, ks, stride, pl, pr),
+                                         Cin, Cexp, ks, stride) > 0
 
 
 def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, ks, stride=1, pad=(0, 0, 0, 0), want_partial=False,

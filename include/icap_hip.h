@@ -105,6 +105,11 @@ int icap_expand_dwconv_f32(const float* x, const float* w_exp, const float* exp_
                            int B, int H, int W, int Cin, int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho,
                            int Wo, void* stream);
 int icap_expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int stride);
+/* 1 when icap_expand_dwconv_f32 runs this layer on its whole-image kernel: the stride-1 blocks at 14 x 14 (80 / 112 input
+ * channels) and 7 x 7 (192), 3x3 or 5x5 with pad = KS / 2, where a workgroup owns whole images (one 14 x 14 or four 7 x 7)
+ * and 64 expanded channels, so no halo is recomputed; one chunk per image (partial [B][1][Cexp] = the channel sums).
+ * That kernel takes and gives fp32 tensors only: the bf16 entry point rejects these shapes. */
+int icap_expand_dwconv_whole_image(int H, int W, int Cin, int Cexp, int KS, int stride);
 
 /* EfficientNet-B0 stem fused with block 0's depthwise convolution: 3x3 stride-2 convolution of the 4-channel-padded
  * image x [B][img_h][img_w][4] with w_stem [C][3][3][4] (TF-"same" padding stem_pad_t / stem_pad_l at the top / left,

@@ -1,10 +1,11 @@
 """Run the fused expand + depthwise kernel on one EfficientNet-B0 block shape a few times; meant to sit under rocprofv3 --pmc.
-usage: xd_one.py <block 1..5> [batch]"""
+usage: xd_one.py <block 1..10> [batch]   (6..10: the whole-image kernel of the 14x14 / 7x7 blocks)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from image_captioning_amd import ops
 from image_captioning_amd.backbones import same_pad
-SHAPES = {1: (112, 16, 96, 3, 2), 2: (56, 24, 144, 3, 1), 3: (56, 24, 144, 5, 2), 4: (28, 40, 240, 5, 1), 5: (28, 40, 240, 3, 2)}
+SHAPES = {1: (112, 16, 96, 3, 2), 2: (56, 24, 144, 3, 1), 3: (56, 24, 144, 5, 2), 4: (28, 40, 240, 5, 1), 5: (28, 40, 240, 3, 2),
+          6: (14, 80, 480, 3, 1), 7: (14, 80, 480, 5, 1), 8: (14, 112, 672, 5, 1), 9: (7, 192, 1152, 5, 1), 10: (7, 192, 1152, 3, 1)}
 H, Cin, Cexp, ks, s = SHAPES[int(sys.argv[1])]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 d = torch.device("cuda:0")

@@ -83,8 +83,8 @@ SIGNATURES = {
     "icap_linear_bf16_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "icap_to_bf16_f32": (_i, [_p, _p, _ll, _p]),
     "icap_split3_f32": (_i, [_p, _p, _ll, _p]),
-    "icap_linear_f32x3_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
-    "icap_linear_f32x3_argmax_f32": (_i, [_p] * 7 + [_i, _i, _i, _p]),
+    "icap_linear_f32x3_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "icap_linear_f32x3_argmax_f32": (_i, [_p, _i] + [_p] * 6 + [_i, _i, _i, _p]),
     "icap_linear_bf16_argmax_f32": (_i, [_p] * 7 + [_i, _i, _i, _p]),
     "icap_linear_bf16_argmax_parts": (_i, [_i]),
     "icap_topk_sample_f32": (_i, [_p, _i, _i, _i, _i, C.c_ulonglong, C.c_ulonglong, _p, _p, _p, _i, _p]),

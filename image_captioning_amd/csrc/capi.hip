@@ -40,9 +40,10 @@ int linear_bf16_f32(const void*, int, const unsigned short*, const float*, const
                     int, int, int, int, hipStream_t);
 int to_bf16_f32(const float*, unsigned short*, long long, hipStream_t);
 int split3_f32(const float*, unsigned short*, long long, hipStream_t);
-int linear_f32x3_f32(const float*, const unsigned short*, const float*, const float*, const float*, const float*, int, float*, int, int,
-                     int, int, int, hipStream_t);
-int linear_f32x3_argmax_f32(const float*, const unsigned short*, const float*, const float*, float*, float*, int*, int, int, int, hipStream_t);
+int linear_f32x3_f32(const float*, int, const unsigned short*, const float*, const float*, const float*, const float*, int, float*, int,
+                     int, int, int, int, hipStream_t);
+int linear_f32x3_argmax_f32(const float*, int, const unsigned short*, const float*, const float*, float*, float*, int*, int, int, int,
+                            hipStream_t);
 int conv2d_bf16_f32(const void*, const unsigned short*, const float*, const float*, const void*, void*, int, int, int, int, int, int,
                     int, int, int, int, int, int, int, int, int, hipStream_t);
 int maxpool2d_bf16(const unsigned short*, unsigned short*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -205,14 +206,15 @@ int icap_linear_bf16_argmax_parts(int N) { return linear_bf16_argmax_parts(N); }
 
 int icap_split3_f32(const float* src, unsigned short* dst, long long n, void* stream) { return split3_f32(src, dst, n, (hipStream_t)stream); }
 
-int icap_linear_f32x3_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
-                          const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, void* stream) {
-    return linear_f32x3_f32(x, w3, scale, bias, residual, gate, hw, y, M, K, N, act, cfg, (hipStream_t)stream);
+int icap_linear_f32x3_f32(const void* x, int x_split, const unsigned short* w3, const float* scale, const float* bias,
+                          const float* residual, const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg,
+                          void* stream) {
+    return linear_f32x3_f32((const float*)x, x_split, w3, scale, bias, residual, gate, hw, y, M, K, N, act, cfg, (hipStream_t)stream);
 }
 
-int icap_linear_f32x3_argmax_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, float* y,
-                                 float* part_val, int* part_idx, int M, int K, int N, void* stream) {
-    return linear_f32x3_argmax_f32(x, w3, scale, bias, y, part_val, part_idx, M, K, N, (hipStream_t)stream);
+int icap_linear_f32x3_argmax_f32(const void* x, int x_split, const unsigned short* w3, const float* scale, const float* bias,
+                                 float* y, float* part_val, int* part_idx, int M, int K, int N, void* stream) {
+    return linear_f32x3_argmax_f32((const float*)x, x_split, w3, scale, bias, y, part_val, part_idx, M, K, N, (hipStream_t)stream);
 }
 
 int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* stream) {

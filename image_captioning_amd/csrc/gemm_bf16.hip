@@ -80,12 +80,14 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // by a few units of fp32 rounding, at 6/16 of the fp32 MFMA's cost per multiply-add (v_mfma_f32_32x32x2_f32 retires
 // 64 flop per cycle and SIMD, v_mfma_f32_32x32x16_bf16 1024).  x is split while it is staged (three LDS planes), w points
 // to three pre-split planes [3][N][K].
+// With A16 the activations arrive pre-split too ([3][M][K] planes from split3_f32): a GEMM with many column tiles (the
+// decoder's vocabulary projection: 53) would otherwise repeat the split arithmetic of x in every one of them.
 // Its three operand planes are single-buffered in LDS (60 KB for a 128 x 128 x 32 tile) so that TWO workgroups share a CU:
 // one workgroup's staging phase (global-load wait, the split arithmetic, LDS stores) runs under the other's MFMA phase.
 template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, int CONV = 0, int SPLIT = 1>
 __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(const GemmBf16Params p) {
     static_assert(!(CONV && (GATE || AMAX)) && !(CONV == 2 && A16), "the convolution form has no gate / arg-max; its 4-channel form reads fp32");
-    static_assert(SPLIT == 1 || (SPLIT == 3 && !A16 && CONV == 0), "split products: fp32 activations, linear form");
+    static_assert(SPLIT == 1 || (SPLIT == 3 && CONV == 0 && !(A16 && GATE)), "split products: linear form; pre-split activations take no gate");
     constexpr int BK = GB16_BK, LDK = GB16_LDK;
     constexpr int TM = BM / 2, TN = BN / 2, RM = TM / 32, RN = TN / 32;
     constexpr int AP = BM / 32;                    // staging passes over A: thread t -> row t/8 + 32 i, floats 4 (t%8) ..
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
     constexpr int NSET = 1;                          // staging register sets (K slices in flight)
     float4 ra[NSET][AP], rg[NSET][GATE ? AP : 1];
     uint4 rb[NSET][SPLIT][BP];
-    uint4 ra16[A16 ? AP16 : 1];
+    uint4 ra16[A16 ? SPLIT : 1][A16 ? AP16 : 1];
     float4 rg16[(A16 && GATE) ? AP16 : 1][2];
     unsigned okmask_s[NSET];
     // every load is unconditional (clamped address); out-of-range elements are zeroed when the slice goes to LDS
@@ -194,7 +196,9 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                     ok = a16_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                     src = a16_src[i] + ((size_t)ih * p.W + iw) * p.Cin + c_c0 + b_k8;
                 }
-                ra16[i] = *reinterpret_cast<const uint4*>(ok ? src : reinterpret_cast<const unsigned short*>(p.x));
+#pragma unroll
+                for (int sp = 0; sp < SPLIT; ++sp)
+                    ra16[sp][i] = *reinterpret_cast<const uint4*>(ok ? src + (size_t)sp * p.M * p.K : reinterpret_cast<const unsigned short*>(p.x));
                 if constexpr (GATE) {
                     rg16[i][0] = *reinterpret_cast<const float4*>(ok ? g16_src[i] + kb : p.gate);
                     rg16[i][1] = *reinterpret_cast<const float4*>(ok ? g16_src[i] + kb + 4 : p.gate);
@@ -246,7 +250,11 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
 #pragma unroll
             for (int i = 0; i < AP16; ++i) {
                 if (BM % 64 == 0 || b_row + 64 * i < BM) {
-                    uint4 o = ra16[i];
+#pragma unroll
+                    for (int sp = 1; sp < SPLIT; ++sp)
+                        *reinterpret_cast<uint4*>(&As[sp * APL + (buf * BM + b_row + 64 * i) * LDK + b_k8]) =
+                            ((okmask >> i) & 1u) ? ra16[sp][i] : make_uint4(0u, 0u, 0u, 0u);
+                    uint4 o = ra16[0][i];
                     if constexpr (GATE) {   // bf16 -> fp32 is a 16-bit shift; multiply by the gate, round back
                         const unsigned w[4] = {o.x, o.y, o.z, o.w};
                         const float g[8] = {rg16[i][0].x, rg16[i][0].y, rg16[i][0].z, rg16[i][0].w,
@@ -582,16 +590,16 @@ constexpr int gb16_split_smem() {
     return stage > ep ? stage : ep;
 }
 
-template <int BM, int BN, bool GATE, bool AMAX>
+template <int BM, int BN, bool GATE, bool AMAX, bool A3 = false>
 static int gb16_split_launch(GemmBf16Params& p, hipStream_t st) {
-    static hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, GATE, AMAX, false, 0, 3>),
+    static hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, GATE, AMAX, A3, 0, 3>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, gb16_split_smem<BM, BN>());
     if (attr_rc != hipSuccess) { set_error("linear_f32x3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr_rc)); return ICAP_ERR_HIP_BASE + (int)attr_rc; }
     p.tiles_n = (p.N + BN - 1) / BN;
-    gb16_set_order(p, 4, 6);
+    gb16_set_order(p, A3 ? 6 : 4, 6);
     const dim3 grid((unsigned)((long long)((p.M + BM - 1) / BM) * p.tiles_n)), block(256);
     constexpr int lds_bytes = gb16_split_smem<BM, BN>();
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, GATE, AMAX, false, 0, 3>), grid, block, lds_bytes, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, GATE, AMAX, A3, 0, 3>), grid, block, lds_bytes, st, p);
     return launch_status("linear_f32x3");
 }
 
@@ -609,9 +617,10 @@ static int split_args_ok(const char* what, const float* x, const unsigned short*
 }
 
 // cfg: -1 = choose by shape, 0 = 128x128, 1 = 64x128, 2 = 64x64 tiles
-int linear_f32x3_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
+int linear_f32x3_f32(const float* x, int x_split, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
                      const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, hipStream_t st) {
-    if (!y || (gate && hw <= 0)) { set_error("linear_f32x3: bad arguments"); return ICAP_ERR_ARG; }
+    if (!y || (gate && hw <= 0) || (gate && x_split)) { set_error("linear_f32x3: bad arguments (pre-split activations take no gate)"); return ICAP_ERR_ARG; }
+    if (x_split && (((size_t)M * K * 2) & 15)) { set_error("linear_f32x3: every activation plane must be 16-byte aligned"); return ICAP_ERR_ALIGN; }
     const int rc = split_args_ok("linear_f32x3", x, w3, scale, bias, residual, gate, y, M, K, N);
     if (rc != ICAP_OK) return rc;
     GemmBf16Params p{x, w3, scale, bias, residual, gate, y, M, N, K, gate ? hw : 1, act, 0, nullptr, nullptr};
@@ -619,6 +628,14 @@ int linear_f32x3_f32(const float* x, const unsigned short* w3, const float* scal
         const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
         const int waste = (N + 127) / 128 * 128 - N;            // columns of the last 128-wide tile that are padding
         cfg = (t128 >= 192 && waste * 4 <= N) ? 0 : ((long long)((M + 63) / 64) * ((N + 127) / 128) >= 192 && waste * 4 <= N ? 1 : 2);
+    }
+    if (x_split) {
+        switch (cfg) {
+            case 0: return gb16_split_launch<128, 128, false, false, true>(p, st);
+            case 1: return gb16_split_launch<64, 128, false, false, true>(p, st);
+            case 2: return gb16_split_launch<64, 64, false, false, true>(p, st);
+            default: set_error("linear_f32x3: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
+        }
     }
     switch (cfg) {
         case 0: return gate ? gb16_split_launch<128, 128, true, false>(p, st) : gb16_split_launch<128, 128, false, false>(p, st);
@@ -629,12 +646,14 @@ int linear_f32x3_f32(const float* x, const unsigned short* w3, const float* scal
 }
 
 // vocabulary projection with arg-max partials per 128-column tile (linear_bf16_argmax_parts(N) per row)
-int linear_f32x3_argmax_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, float* y, float* part_val,
-                            int* part_idx, int M, int K, int N, hipStream_t st) {
+int linear_f32x3_argmax_f32(const float* x, int x_split, const unsigned short* w3, const float* scale, const float* bias, float* y,
+                            float* part_val, int* part_idx, int M, int K, int N, hipStream_t st) {
     if (!part_val || !part_idx) { set_error("linear_f32x3_argmax: null partial buffers"); return ICAP_ERR_ARG; }
+    if (x_split && (((size_t)M * K * 2) & 15)) { set_error("linear_f32x3_argmax: every activation plane must be 16-byte aligned"); return ICAP_ERR_ALIGN; }
     const int rc = split_args_ok("linear_f32x3_argmax", x, w3, scale, bias, nullptr, nullptr, y, M, K, N);
     if (rc != ICAP_OK) return rc;
     GemmBf16Params p{x, w3, scale, bias, nullptr, nullptr, y, M, N, K, 1, ACT_NONE, 0, part_val, part_idx};
+    if (x_split) return M > 64 ? gb16_split_launch<128, 128, false, true, true>(p, st) : gb16_split_launch<64, 128, false, true, true>(p, st);
     return M > 64 ? gb16_split_launch<128, 128, false, true>(p, st) : gb16_split_launch<64, 128, false, true>(p, st);
 }
 

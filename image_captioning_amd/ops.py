@@ -593,11 +593,20 @@ def split3(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _x_planes(x):
+    """(M, K, pre-split?) of an activation operand: an fp32 [M, K] matrix or its split3 planes, bf16 [3, M, K]."""
+    if x.dtype == torch.bfloat16:
+        if x.dim() != 3 or x.shape[0] != 3:
+            raise IcapError("linear_f32x3: bf16 activations must be split3(x) planes [3, M, K]")
+        return x.shape[1], x.shape[2], True
+    return x.shape[0], x.shape[1], False
+
+
 def linear_f32x3(x, w3, bias=None, scale=None, act=ACT_NONE, residual=None, gate=None, hw=1, out=None, cfg=-1):
     """y[M,N] = act((x[M,K] (* gate[m // hw]) @ w[N,K]^T) * scale + bias (+ residual)), fp32-accurate, on the bf16 matrix
-    cores: six exact bf16 products per multiply from three-way splits of both operands (w3 = split3(w), x split on the
-    fly), fp32 accumulation."""
-    M, K = x.shape
+    cores: six exact bf16 products per multiply from three-way splits of both operands (w3 = split3(w); x fp32 and split
+    on the fly, or split3(x) planes - no gate then), fp32 accumulation."""
+    M, K, pre = _x_planes(x)
     if w3.dtype != torch.bfloat16 or w3.dim() < 2 or w3.shape[0] != 3 or w3.numel() // (3 * w3.shape[1]) != K:
         raise IcapError(f"linear_f32x3: w3 must be split3(w) of a [N, {K}] weight")
     Nn = w3.shape[1]
@@ -605,19 +614,20 @@ def linear_f32x3(x, w3, bias=None, scale=None, act=ACT_NONE, residual=None, gate
         out = torch.empty((M, Nn), device=x.device, dtype=torch.float32)
     if residual is not None and residual.numel() != M * Nn:
         raise IcapError("linear_f32x3: residual has the wrong size")
-    if gate is not None and (gate.shape[-1] != K or gate.shape[0] * hw != M):
-        raise IcapError("linear_f32x3: gate must be [M // hw, K]")
+    if gate is not None and (pre or gate.shape[-1] != K or gate.shape[0] * hw != M):
+        raise IcapError("linear_f32x3: gate must be [M // hw, K] (and x fp32)")
     span = _Span("linear_f32x3", (M, K, Nn, residual is not None, gate is not None))
-    N.check(N.load().icap_linear_f32x3_f32(_ck(x, "x"), _ck(w3, "w3", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
-                                           _ck(residual, "residual"), _ck(gate, "gate"), hw, _ck(out, "out"), M, K, Nn, act, cfg,
-                                           _stream()), "linear_f32x3")
+    N.check(N.load().icap_linear_f32x3_f32(_ck(x, "x", x.dtype), int(pre), _ck(w3, "w3", torch.bfloat16), _ck(scale, "scale"),
+                                           _ck(bias, "bias"), _ck(residual, "residual"), _ck(gate, "gate"), hw, _ck(out, "out"), M, K,
+                                           Nn, act, cfg, _stream()), "linear_f32x3")
     span.done()
     return out
 
 
 def linear_f32x3_argmax(x, w3, bias=None, scale=None, want_logits=False):
-    """fp32-accurate vocabulary projection (split bf16 products) with fused arg-max partials per 128-column tile."""
-    M, K = x.shape
+    """fp32-accurate vocabulary projection (split bf16 products) with fused arg-max partials per 128-column tile; x fp32
+    [M, K] or its split3 planes."""
+    M, K, pre = _x_planes(x)
     Nn = w3.shape[1]
     lib = N.load()
     P = lib.icap_linear_bf16_argmax_parts(Nn)
@@ -625,9 +635,9 @@ def linear_f32x3_argmax(x, w3, bias=None, scale=None, want_logits=False):
     pi = torch.empty((M, P), device=x.device, dtype=torch.int32)
     logits = torch.empty((M, Nn), device=x.device, dtype=torch.float32) if want_logits else None
     span = _Span("linear_f32x3", (M, K, Nn, False, False))
-    N.check(lib.icap_linear_f32x3_argmax_f32(_ck(x, "x"), _ck(w3, "w3", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
-                                             _ck(logits, "logits"), _ck(pv, "pv"), _ck(pi, "pi", torch.int32), M, K, Nn, _stream()),
-            "linear_f32x3_argmax")
+    N.check(lib.icap_linear_f32x3_argmax_f32(_ck(x, "x", x.dtype), int(pre), _ck(w3, "w3", torch.bfloat16), _ck(scale, "scale"),
+                                             _ck(bias, "bias"), _ck(logits, "logits"), _ck(pv, "pv"), _ck(pi, "pi", torch.int32), M, K, Nn,
+                                             _stream()), "linear_f32x3_argmax")
     span.done()
     return pv, pi, logits
 

@@ -194,15 +194,18 @@ int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* s
  * the six products hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi are exact in the MFMA's fp32 accumulation and the three
  * dropped ones are each <= 2^-24 of the product, so the result differs from an fp32 dot product by a few units of fp32
  * rounding.  icap_split3_f32 prepares the weights once: src fp32 [n] -> dst bf16 [3][n] (n even).  The activations x stay
- * fp32 in memory and are split while they are staged.  Same epilogue as icap_conv2d_f32 / icap_linear_argmax_f32
+ * fp32 in memory and are split while they are staged (x_split = 0), or arrive as the three planes [3][M][K] icap_split3_f32
+ * makes of them (x_split = 1, no gate): worth it when the result has many column tiles, each of which would repeat the
+ * split arithmetic (the decoder's vocabulary projection: 53).  Same epilogue as icap_conv2d_f32 / icap_linear_argmax_f32
  * (scale, bias, residual, gate [M/hw][K], activation; arg-max partials per 128-column tile:
  * icap_linear_bf16_argmax_parts(N) per row).  K % 8 == 0, N % 4 == 0.  cfg: -1 = by shape, 0 = 128x128, 1 = 64x128,
  * 2 = 64x64 tiles.  Replaces the same nn.Linear / 1x1 convolution sites as icap_conv2d_f32. */
 int icap_split3_f32(const float* src, unsigned short* dst, long long n, void* stream);
-int icap_linear_f32x3_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
-                          const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, void* stream);
-int icap_linear_f32x3_argmax_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, float* y,
-                                 float* part_val, int* part_idx, int M, int K, int N, void* stream);
+int icap_linear_f32x3_f32(const void* x, int x_split, const unsigned short* w3, const float* scale, const float* bias,
+                          const float* residual, const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg,
+                          void* stream);
+int icap_linear_f32x3_argmax_f32(const void* x, int x_split, const unsigned short* w3, const float* scale, const float* bias,
+                                 float* y, float* part_val, int* part_idx, int M, int K, int N, void* stream);
 
 /* bf16-product form of icap_conv2d_f32 for the dense KH x KW convolutions of the ResNet-18 / VGG-16 encoders
  * (seq2seqbasic.py:19-35: torchvision conv3x3 + BN + ReLU, residual add): x [B][H][W][Cin] NHWC with Cin % 32 == 0,

@@ -397,3 +397,20 @@ def test_linear_f32x3_argmax(M, K, N):
     assert torch.equal(ids[:, 0].cpu()[clear], ref.argmax(1)[clear])
     pv2, pi2, none = ops.linear_f32x3_argmax(x.to(d), ops.split3(w.to(d)), b.to(d))
     assert none is None and torch.equal(pv2, pv) and torch.equal(pi2, pi)
+
+
+def test_linear_f32x3_with_presplit_activations():
+    """The split-product GEMM fed with split3(x) planes gives bit-identical results to splitting x inside the kernel
+    (the same three planes either way), for the plain and the arg-max form."""
+    from image_captioning_amd import ops
+    d = dev()
+    M, K, Nn = 300, 512, 1000
+    x, w, b = rnd(M, K, seed=1).to(d), rnd(Nn, K, seed=2, scale=K ** -0.5).to(d), rnd(Nn, seed=3).to(d)
+    w3, x3 = ops.split3(w), ops.split3(x)
+    for cfg in (0, 1, 2):
+        assert torch.equal(ops.linear_f32x3(x3, w3, b, act=ops.ACT_RELU, cfg=cfg), ops.linear_f32x3(x, w3, b, act=ops.ACT_RELU, cfg=cfg))
+    pv0, pi0, lg0 = ops.linear_f32x3_argmax(x, w3, b, want_logits=True)
+    pv1, pi1, lg1 = ops.linear_f32x3_argmax(x3, w3, b, want_logits=True)
+    assert torch.equal(pv0, pv1) and torch.equal(pi0, pi1) and torch.equal(lg0, lg1)
+    with pytest.raises(ops.IcapError):
+        ops.linear_f32x3(x3, w3, gate=torch.ones(M, K, device=d))

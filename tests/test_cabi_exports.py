@@ -37,6 +37,9 @@ def test_argument_checks_need_no_gpu():
     assert rc == 1 and b"null" in lib.icap_last_error()
     assert lib.icap_gemv_blocks(6756) > 0
     assert lib.icap_dwconv_chunks(112, 112, 32, 3, 1) > 0 and lib.icap_dwconv_chunks(7, 7, 1152, 5, 1) == 7
-    assert lib.icap_expand_dwconv_chunks(56, 56, 16, 96, 3, 2) == 56 and lib.icap_expand_dwconv_chunks(14, 14, 80, 480, 3, 1) == -1
+    assert lib.icap_expand_dwconv_chunks(56, 56, 16, 96, 3, 2) == 56 and lib.icap_expand_dwconv_chunks(14, 14, 112, 672, 5, 2) == -1
+    # the stride-1 blocks at 14x14 / 7x7 run on the whole-image kernel: one chunk (the channel sums) per image
+    assert lib.icap_expand_dwconv_chunks(14, 14, 80, 480, 3, 1) == 1 and lib.icap_expand_dwconv_whole_image(7, 7, 192, 1152, 5, 1) == 1
+    assert lib.icap_expand_dwconv_whole_image(28, 28, 40, 240, 5, 1) == 0
     assert lib.icap_stem_dwconv_chunks(112, 112, 32) == 64
     assert lib.icap_greedy_tfm_ws_floats(8, 512, 2048, 6756) > 8 * 512 * 4

@@ -128,6 +128,8 @@ WORK = {"linear_f32x3": linear_x3_work, "linear_bf16": lambda s: linear_bf16_wor
         "scale_bias_act": lambda s: (2.0 * s[0] * s[1], 4.0 * s[0] * s[1] * (3 if s[2] else 2)),
         "bn_act_bwd": lambda s: (8.0 * s[0] * s[1], 4.0 * s[0] * s[1] * 3),
         "chan_affine": lambda s: (2.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * (2 if s[3] else 1)),
+        "se_train_fwd": lambda s: (4.0 * s[0] * s[1] * s[2], 4.0 * (3 * s[0] * s[1] + 2 * s[1] * s[2])),
+        "se_train_bwd": lambda s: (8.0 * s[0] * s[1] * s[2], 4.0 * (5 * s[0] * s[1] + 4 * s[1] * s[2])),
         "image_dot": lambda s: (2.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * (2 if s[3] else 1)),
         "dwconv_bwd_data": lambda s: (2.0 * s[0] * s[6] * s[7] * s[3] * s[4] * s[4], 4.0 * s[3] * s[0] * (s[1] * s[2] + s[6] * s[7])),
         "dwconv_bwd_weight": lambda s: (2.0 * s[0] * s[6] * s[7] * s[3] * s[4] * s[4], 4.0 * s[3] * s[0] * (s[1] * s[2] + s[6] * s[7]))}

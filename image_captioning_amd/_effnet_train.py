@@ -86,11 +86,7 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
     wr, br = _w2d(blk._se_reduce), blk._se_reduce.bias.detach().float().contiguous()
     we, be = _w2d(blk._se_expand), blk._se_expand.bias.detach().float().contiguous()
     pooled = T.image_dot(a1, None, B, HW, mid, scale=1.0 / HW)
-    # the squeeze width (cin / 4) is not a multiple of 4 everywhere: these two tiny layers use the general GEMM
-    r_pre = T.scale_bias_act(T.gemm_nn(pooled, wr.t().contiguous()), None, br)
-    r = T.scale_bias_act(r_pre, act=ACT_SWISH)
-    e = T.scale_bias_act(T.gemm_nn(r, we.t().contiguous()), None, be)
-    gate = T.scale_bias_act(e, act=ACT_SIGMOID)
+    r_pre, e, gate = T.se_train_fwd(pooled, wr, br, we, be)          # reduce FC + swish + expand FC + sigmoid in one launch
     a2 = T.chan_affine(a1, gate, None, 0.0, B, HW, mid)
     z2, proj_bwd = _conv1x1(tape, a2, blk._project_conv)
     y, bn2_bwd = _bn_act(tape, z2, blk._bn2, ACT_NONE)
@@ -113,14 +109,11 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
         dz2 = bn2_bwd(dyb)
         da2 = proj_bwd(dz2)
         dgate = T.image_dot(da2, a1, B, HW, mid)
-        de = T.act_bwd(dgate, e, ACT_SIGMOID)
-        tape.grad(blk._se_expand.weight, T.gemm_tn(de, r))
-        tape.grad(blk._se_expand.bias, T.col_sum(de))
-        dr = T.gemm_nn(de, we)
-        dr_pre = T.act_bwd(dr, r_pre, ACT_SWISH)
-        tape.grad(blk._se_reduce.weight, T.gemm_tn(dr_pre, pooled))
-        tape.grad(blk._se_reduce.bias, T.col_sum(dr_pre))
-        dpooled = T.gemm_nn(dr_pre, wr)
+        dpooled, dwe, dbe, dwr, dbr = T.se_train_bwd(dgate, e, r_pre, pooled, wr, we)
+        tape.grad(blk._se_expand.weight, dwe)
+        tape.grad(blk._se_expand.bias, dbe)
+        tape.grad(blk._se_reduce.weight, dwr)
+        tape.grad(blk._se_reduce.bias, dbr)
         da1 = T.chan_affine(da2, gate, dpooled, 1.0 / HW, B, HW, mid)
         dz1 = bn1_bwd(da1)
         dww = T.dwconv_bwd_weight(dz1, a0, B, H, W, mid, k, stride, lo, lo, Ho, Wo)

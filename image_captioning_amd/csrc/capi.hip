@@ -122,6 +122,10 @@ int embedding_bwd_f32(const long long*, const float*, int, int, int, int, float*
 int chan_affine_f32(const float*, const float*, const float*, float, int, int, int, float*, hipStream_t);
 int image_dot_f32(const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
 long long image_dot_ws_floats(int, int, int);
+int se_train_fwd_f32(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
+                     hipStream_t);
+int se_train_bwd_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
+                     float*, float*, float*, float*, int, int, int, hipStream_t);
 int dwconv_bwd_data_f32(const float*, const float*, int, int, int, int, int, int, int, int, int, int, float*, hipStream_t);
 int dwconv_bwd_weight_f32(const float*, const float*, int, int, int, int, int, int, int, int, int, int, float*, float*, hipStream_t);
 long long dwconv_bwd_weight_ws_floats(int, int, int, int, int);
@@ -686,6 +690,17 @@ int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, flo
     return image_dot_f32(x, y, B, HW, C, scale, out, ws, (hipStream_t)stream);
 }
 long long icap_image_dot_ws_floats(int B, int HW, int C) { return image_dot_ws_floats(B, HW, C); }
+
+int icap_se_train_fwd_f32(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* r_pre,
+                          float* e, float* gate, int B, int C, int S, void* stream) {
+    return se_train_fwd_f32(pooled, wr, br, we, be, r_pre, e, gate, B, C, S, (hipStream_t)stream);
+}
+
+int icap_se_train_bwd_f32(const float* dgate, const float* e, const float* r_pre, const float* pooled, const float* wr,
+                          const float* we, float* de, float* dr_pre, float* dpooled, float* dwe, float* dbe, float* dwr, float* dbr,
+                          int B, int C, int S, void* stream) {
+    return se_train_bwd_f32(dgate, e, r_pre, pooled, wr, we, de, dr_pre, dpooled, dwe, dbe, dwr, dbr, B, C, S, (hipStream_t)stream);
+}
 
 int icap_dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, int C, int K, int S, int pad_t, int pad_l, int Ho,
                              int Wo, float* dx, void* stream) {

@@ -385,4 +385,174 @@ int transpose_f32(const float* src, int rows, int cols, int ld_src, float* dst, 
     return launch_status("transpose");
 }
 
+// ---------------------------------------------------------------- squeeze-excite in training mode
+// efficientnet_pytorch's squeeze-excite branch of an MBConv block: pooled -> _se_reduce (1x1 conv = FC, bias) -> swish ->
+// _se_expand (FC, bias) -> sigmoid -> gate.  As separate launches it is six tiny kernels forward and eight backward per
+// block, each a few microseconds of launch latency on a [B, C] problem; here it is one kernel forward and two backward.
+// Weights in the parameters' own layout: wr [S][C] (= _se_reduce.weight), we [C][S] (= _se_expand.weight).
+constexpr int SET_MAX_C = 2048, SET_MAX_S = 128;
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one workgroup per image: r_pre = wr . pooled + br, e = we . swish(r_pre) + be, gate = sigmoid(e)
+__global__ __launch_bounds__(256) void se_train_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
+                                                           const float* __restrict__ br, const float* __restrict__ we,
+                                                           const float* __restrict__ be, float* __restrict__ r_pre,
+                                                           float* __restrict__ e, float* __restrict__ gate, int C, int S) {
+    __shared__ float pl[SET_MAX_C];
+    __shared__ float sq[SET_MAX_S];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int c = tid; c < C; c += 256) pl[c] = pooled[(size_t)b * C + c];
+    __syncthreads();
+    for (int j = wave; j < S; j += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(wr[(size_t)j * C + c], pl[c], a);
+        a = wave_sum_f(a) + br[j];
+        if (lane == 0) {
+            r_pre[(size_t)b * S + j] = a;
+            sq[j] = a * sigmoid_fast(a);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = be[c];
+        const float* w = we + (size_t)c * S;
+        for (int j = 0; j < S; ++j) a = fmaf(w[j], sq[j], a);
+        e[(size_t)b * C + c] = a;
+        gate[(size_t)b * C + c] = sigmoid_fast(a);
+    }
+}
+
+// one workgroup per image: de = dgate * sigmoid'(e); dr_pre = (we^T de) * swish'(r_pre); dpooled = wr^T dr_pre
+__global__ __launch_bounds__(256) void se_train_bwd_image_kernel(const float* __restrict__ dgate, const float* __restrict__ e,
+                                                                 const float* __restrict__ r_pre, const float* __restrict__ wr,
+                                                                 const float* __restrict__ we, float* __restrict__ de,
+                                                                 float* __restrict__ dr_pre, float* __restrict__ dpooled, int C,
+                                                                 int S) {
+    __shared__ float dl[SET_MAX_C];
+    __shared__ float dr[SET_MAX_S];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int c = tid; c < C; c += 256) {
+        const float g = sigmoid_fast(e[(size_t)b * C + c]);
+        const float d = dgate[(size_t)b * C + c] * g * (1.f - g);
+        dl[c] = d;
+        de[(size_t)b * C + c] = d;
+    }
+    __syncthreads();
+    for (int j = wave; j < S; j += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(we[(size_t)c * S + j], dl[c], a);
+        a = wave_sum_f(a);
+        if (lane == 0) {
+            const float x = r_pre[(size_t)b * S + j], sg = sigmoid_fast(x);
+            const float d = a * sg * (1.f + x * (1.f - sg));
+            dr[j] = d;
+            dr_pre[(size_t)b * S + j] = d;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < S; ++j) a = fmaf(wr[(size_t)j * C + c], dr[j], a);
+        dpooled[(size_t)b * C + c] = a;
+    }
+}
+
+// parameter gradients: a workgroup owns 64 channels x 16 squeeze units; its 256 threads are 64 channels x 4 image slices
+// (image b goes to slice b mod 4), each slice sums its images in order and the four slices are added in order
+__global__ __launch_bounds__(256) void se_train_bwd_weights_kernel(const float* __restrict__ de, const float* __restrict__ dr_pre,
+                                                                   const float* __restrict__ r_pre, const float* __restrict__ pooled,
+                                                                   float* __restrict__ dwe, float* __restrict__ dbe,
+                                                                   float* __restrict__ dwr, float* __restrict__ dbr, int B, int C,
+                                                                   int S) {
+    constexpr int SG = 16, BT = 64;
+    __shared__ float rl[BT][SG], dl[BT][SG];
+    __shared__ float red[3][64][2 * SG + 1];
+    const int tid = threadIdx.x, cl = tid & 63, slice = tid >> 6;
+    const int c = blockIdx.x * 64 + cl, s0 = blockIdx.y * SG;
+    const bool ok = c < C;
+    float awe[SG], awr[SG], sbe = 0.f;
+#pragma unroll
+    for (int j = 0; j < SG; ++j) { awe[j] = 0.f; awr[j] = 0.f; }
+    for (int b0 = 0; b0 < B; b0 += BT) {
+        __syncthreads();
+        for (int i = tid; i < BT * SG; i += 256) {
+            const int bb = i / SG, j = i - bb * SG;
+            const bool in = b0 + bb < B && s0 + j < S;
+            const float x = in ? r_pre[(size_t)(b0 + bb) * S + s0 + j] : 0.f;
+            rl[bb][j] = x * sigmoid_fast(x);
+            dl[bb][j] = in ? dr_pre[(size_t)(b0 + bb) * S + s0 + j] : 0.f;
+        }
+        __syncthreads();
+        const int nb = min(BT, B - b0);
+        for (int bb = slice; bb < nb; bb += 4) {
+            const float d = ok ? de[(size_t)(b0 + bb) * C + c] : 0.f;
+            const float pv = ok ? pooled[(size_t)(b0 + bb) * C + c] : 0.f;
+            sbe += d;
+#pragma unroll
+            for (int j = 0; j < SG; ++j) {
+                awe[j] = fmaf(d, rl[bb][j], awe[j]);
+                awr[j] = fmaf(dl[bb][j], pv, awr[j]);
+            }
+        }
+    }
+    if (slice > 0) {
+#pragma unroll
+        for (int j = 0; j < SG; ++j) { red[slice - 1][cl][j] = awe[j]; red[slice - 1][cl][SG + j] = awr[j]; }
+        red[slice - 1][cl][2 * SG] = sbe;
+    }
+    __syncthreads();
+    if (slice == 0 && ok) {
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int j = 0; j < SG; ++j) { awe[j] += red[k][cl][j]; awr[j] += red[k][cl][SG + j]; }
+            sbe += red[k][cl][2 * SG];
+        }
+#pragma unroll
+        for (int j = 0; j < SG; ++j)
+            if (s0 + j < S) {
+                dwe[(size_t)c * S + s0 + j] = awe[j];
+                dwr[(size_t)(s0 + j) * C + c] = awr[j];
+            }
+        if (blockIdx.y == 0) dbe[c] = sbe;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < S) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dr_pre[(size_t)b * S + tid];
+        dbr[tid] = a;
+    }
+}
+
+static int se_train_args(const char* what, int B, int C, int S) {
+    if (B <= 0 || C <= 0 || S <= 0) { set_error("%s: bad arguments", what); return ICAP_ERR_ARG; }
+    if (C > SET_MAX_C || S > SET_MAX_S) { set_error("%s: C=%d S=%d exceed %d/%d", what, C, S, SET_MAX_C, SET_MAX_S); return ICAP_ERR_LIMIT; }
+    return ICAP_OK;
+}
+
+int se_train_fwd_f32(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* r_pre,
+                     float* e, float* gate, int B, int C, int S, hipStream_t st) {
+    if (!pooled || !wr || !br || !we || !be || !r_pre || !e || !gate) { set_error("se_train_fwd: null pointer"); return ICAP_ERR_ARG; }
+    if (const int rc = se_train_args("se_train_fwd", B, C, S)) return rc;
+    hipLaunchKernelGGL(se_train_fwd_kernel, dim3(B), dim3(256), 0, st, pooled, wr, br, we, be, r_pre, e, gate, C, S);
+    return launch_status("se_train_fwd");
+}
+
+int se_train_bwd_f32(const float* dgate, const float* e, const float* r_pre, const float* pooled, const float* wr, const float* we,
+                     float* de, float* dr_pre, float* dpooled, float* dwe, float* dbe, float* dwr, float* dbr, int B, int C, int S,
+                     hipStream_t st) {
+    if (!dgate || !e || !r_pre || !pooled || !wr || !we || !de || !dr_pre || !dpooled || !dwe || !dbe || !dwr || !dbr) {
+        set_error("se_train_bwd: null pointer");
+        return ICAP_ERR_ARG;
+    }
+    if (const int rc = se_train_args("se_train_bwd", B, C, S)) return rc;
+    hipLaunchKernelGGL(se_train_bwd_image_kernel, dim3(B), dim3(256), 0, st, dgate, e, r_pre, wr, we, de, dr_pre, dpooled, C, S);
+    hipLaunchKernelGGL(se_train_bwd_weights_kernel, dim3((C + 63) / 64, (S + 15) / 16), dim3(256), 0, st, de, dr_pre, r_pre, pooled, dwe,
+                       dbe, dwr, dbr, B, C, S);
+    return launch_status("se_train_bwd");
+}
+
 }  // namespace icap

@@ -299,6 +299,42 @@ def image_dot(x, y, B, HW, C, scale=1.0):
     return out
 
 
+def se_train_fwd(pooled, wr, br, we, be):
+    """Squeeze-excite branch in training mode, one launch: pooled [B, C], wr [S, C], br [S], we [C, S], be [C]
+    -> (r_pre [B, S], e [B, C], gate [B, C]) with r_pre = wr.pooled + br, e = we.swish(r_pre) + be, gate = sigmoid(e)."""
+    B, C = pooled.shape
+    S = wr.shape[0]
+    for t, shape, name in ((wr, (S, C), "wr"), (br, (S,), "br"), (we, (C, S), "we"), (be, (C,), "be")):
+        if tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32 or not t.is_cuda:
+            raise N.IcapError(f"se_train_fwd: {name} must be a contiguous fp32 device tensor of shape {shape}")
+    _ckr(pooled, "pooled")
+    dev = pooled.device
+    r_pre, e, gate = torch.empty(B, S, device=dev), torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+    span = _Span("se_train_fwd", (B, C, S))
+    N.check(N.load().icap_se_train_fwd_f32(pooled.data_ptr(), wr.data_ptr(), br.data_ptr(), we.data_ptr(), be.data_ptr(),
+                                           r_pre.data_ptr(), e.data_ptr(), gate.data_ptr(), B, C, S, _stream()), "se_train_fwd")
+    span.done()
+    return r_pre, e, gate
+
+
+def se_train_bwd(dgate, e, r_pre, pooled, wr, we):
+    """Gradient of se_train_fwd, two launches: -> (dpooled [B, C], dwe [C, S], dbe [C], dwr [S, C], dbr [S])."""
+    B, C = dgate.shape
+    S = wr.shape[0]
+    for t, name in ((dgate, "dgate"), (e, "e"), (r_pre, "r_pre"), (pooled, "pooled"), (wr, "wr"), (we, "we")):
+        if not t.is_contiguous() or t.dtype != torch.float32 or not t.is_cuda:
+            raise N.IcapError(f"se_train_bwd: {name} must be a contiguous fp32 device tensor")
+    dev = dgate.device
+    de, drp, dpooled = torch.empty(B, C, device=dev), torch.empty(B, S, device=dev), torch.empty(B, C, device=dev)
+    dwe, dbe, dwr, dbr = torch.empty(C, S, device=dev), torch.empty(C, device=dev), torch.empty(S, C, device=dev), torch.empty(S, device=dev)
+    span = _Span("se_train_bwd", (B, C, S))
+    N.check(N.load().icap_se_train_bwd_f32(dgate.data_ptr(), e.data_ptr(), r_pre.data_ptr(), pooled.data_ptr(), wr.data_ptr(),
+                                           we.data_ptr(), de.data_ptr(), drp.data_ptr(), dpooled.data_ptr(), dwe.data_ptr(),
+                                           dbe.data_ptr(), dwr.data_ptr(), dbr.data_ptr(), B, C, S, _stream()), "se_train_bwd")
+    span.done()
+    return dpooled, dwe, dbe, dwr, dbr
+
+
 def dwconv_bwd_data(dy, w, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo):
     if S == 1 and Ho == H and Wo == W and C % 4 == 0 and dy.is_contiguous():
         # stride 1: the input gradient is itself a depthwise convolution - of dy with the taps in reverse order and the

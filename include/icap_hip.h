@@ -537,6 +537,19 @@ int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, flo
                        void* stream);
 long long icap_image_dot_ws_floats(int B, int HW, int C);
 
+/* The squeeze-excite branch of an MBConv block in training mode (efficientnet_pytorch MBConvBlock: _se_reduce -> swish ->
+ * _se_expand -> sigmoid, under transformer_word_level_bahdnau.py:12-25 in model.train()), one launch forward and two backward
+ * instead of six and eight tiny ones.  pooled [B][C] (per-image channel means), wr [S][C] = _se_reduce.weight, br [S],
+ * we [C][S] = _se_expand.weight, be [C].  Forward: r_pre [B][S] = wr.pooled + br, e [B][C] = we.swish(r_pre) + be,
+ * gate [B][C] = sigmoid(e).  Backward from dgate [B][C]: de [B][C], dr_pre [B][S] (scratch the caller provides), dpooled [B][C],
+ * and the parameter gradients dwe [C][S], dbe [C], dwr [S][C], dbr [S] (overwritten; images summed in a fixed order).
+ * C <= 2048, S <= 128. */
+int icap_se_train_fwd_f32(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* r_pre,
+                          float* e, float* gate, int B, int C, int S, void* stream);
+int icap_se_train_bwd_f32(const float* dgate, const float* e, const float* r_pre, const float* pooled, const float* wr,
+                          const float* we, float* de, float* dr_pre, float* dpooled, float* dwe, float* dbe, float* dwr, float* dbr,
+                          int B, int C, int S, void* stream);
+
 /* Depthwise convolution gradients (weights [K*K][C], TF-"same" padding given as pad_t / pad_l). */
 int icap_dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, int C, int K, int S, int pad_t,
                              int pad_l, int Ho, int Wo, float* dx, void* stream);

@@ -176,3 +176,29 @@ def test_embedding_gradient_is_deterministic_scatter_add():
     got = T.embedding_bwd(idx.to(D), dy.to(D), V)
     torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
     assert torch.equal(got, T.embedding_bwd(idx.to(D), dy.to(D), V))
+
+
+@pytest.mark.parametrize("B,C,S", [(12, 96, 4), (5, 672, 28), (33, 1152, 48), (3, 32, 8)])
+def test_squeeze_excite_train_forward_backward(B, C, S):
+    """The fused squeeze-excite branch (one launch forward, two backward) against torch autograd."""
+    from image_captioning_amd import train_ops as T
+    pooled = rnd(B, C, seed=20).requires_grad_(True)
+    wr = (rnd(S, C, seed=21) * C ** -0.5).requires_grad_(True)
+    br = (rnd(S, seed=22) * 0.1).requires_grad_(True)
+    we = (rnd(C, S, seed=23) * S ** -0.5).requires_grad_(True)
+    be = (rnd(C, seed=24) * 0.1).requires_grad_(True)
+    r_pre = pooled @ wr.t() + br
+    r = r_pre * torch.sigmoid(r_pre)
+    e = r @ we.t() + be
+    gate = torch.sigmoid(e)
+    dgate = rnd(B, C, seed=25)
+    gate.backward(dgate)
+    g = [t.detach().to(D) for t in (pooled, wr, br, we, be)]
+    rp_g, e_g, gate_g = T.se_train_fwd(*g)
+    torch.testing.assert_close(rp_g.cpu(), r_pre.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(e_g.cpu(), e.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gate_g.cpu(), gate.detach(), rtol=1e-4, atol=1e-5)
+    dpooled, dwe, dbe, dwr, dbr = T.se_train_bwd(dgate.to(D), e_g, rp_g, g[0], g[1], g[3])
+    for got, want, name in ((dpooled, pooled.grad, "dpooled"), (dwe, we.grad, "dwe"), (dbe, be.grad, "dbe"), (dwr, wr.grad, "dwr"),
+                            (dbr, br.grad, "dbr")):
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-5 * max(1.0, want.abs().max().item()), msg=lambda m: f"{name}: {m}")

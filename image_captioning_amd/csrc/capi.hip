@@ -122,6 +122,7 @@ int embedding_bwd_f32(const long long*, const float*, int, int, int, int, float*
 int chan_affine_f32(const float*, const float*, const float*, float, int, int, int, float*, hipStream_t);
 int image_dot_f32(const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
 long long image_dot_ws_floats(int, int, int);
+
 int se_train_fwd_f32(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
                      hipStream_t);
 int se_train_bwd_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,

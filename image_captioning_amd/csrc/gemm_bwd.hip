@@ -477,6 +477,33 @@ static void skinny_launch(const float* a, int lda, const float* b, int ldb, int 
     hipLaunchKernelGGL((gemm_tn_skinny_kernel<MB, NB>), grid, dim3(256), 0, st, a, lda, b, ldb, K, M, N, rpw, ws);
 }
 
+// ---------------------------------------------------------------- short contraction (the reference's loader batch of 12)
+// TN, K <= 16:  C[M][N] (+)= A[K][M]^T . B[K][N] - a sum of K outer products; a thread owns one row and four columns
+template <int KR>
+__global__ __launch_bounds__(256) void gemm_tn_fewk_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                           float* __restrict__ c, int ldc, int M, int N, int K, int accumulate) {
+    const int nq4 = (N + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * nq4) return;
+    const int m = (int)(idx / nq4), n = (int)(idx - (long long)m * nq4) << 2;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        if (k < K) {
+            const float av = a[(size_t)k * lda + m];
+            const float4 bv = *reinterpret_cast<const float4*>(b + (size_t)k * ldb + n);
+            acc.x = fmaf(av, bv.x, acc.x); acc.y = fmaf(av, bv.y, acc.y); acc.z = fmaf(av, bv.z, acc.z); acc.w = fmaf(av, bv.w, acc.w);
+        }
+    }
+    float4* o = reinterpret_cast<float4*>(c + (size_t)m * ldc + n);
+    if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+    *o = acc;
+}
+
+static bool fewrow_ok(const float* b, const float* c, int ldb, int ldc, int N) {
+    return (N & 3) == 0 && (ldb & 3) == 0 && (ldc & 3) == 0 && aligned16(b) && aligned16(c);
+}
+
 // floats of workspace gemm_bwd_f32 needs for this problem (0 when the contraction is not split and the result
 // is not accumulated onto C); sized for either operand layout
 long long gemm_bwd_ws_floats(int M, int N, int K, int accumulate) {
@@ -502,6 +529,12 @@ int gemm_bwd_f32(const float* a, int lda, int a_kmajor, const float* b, int ldb,
         return ICAP_ERR_ARG;
     }
     if (!aligned16(a) || !aligned16(b)) { set_error("gemm_bwd: operands must be 16-byte aligned"); return ICAP_ERR_ALIGN; }
+    if (a_kmajor && K <= 16 && fewrow_ok(b, c, ldb, ldc, N)) {
+        const long long threads = (long long)M * (N / 4);
+        hipLaunchKernelGGL(gemm_tn_fewk_kernel<16>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a, lda, b, ldb, c, ldc, M, N,
+                           K, accumulate);
+        return launch_status("gemm_bwd (short contraction)");
+    }
     if (a_kmajor && skinny_tn(M, N, K)) {
         if (!ws) { set_error("gemm_bwd: workspace required (gemm_bwd_ws_floats)"); return ICAP_ERR_ARG; }
         const int mb = (M + 31) / 32, nb = (N + 31) / 32;

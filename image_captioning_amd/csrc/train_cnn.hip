@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256) void se_train_fwd_kernel(const float* __restri
     __syncthreads();
     for (int j = wave; j < S; j += 4) {
         float a = 0.f;
+#pragma unroll 8
         for (int c = lane; c < C; c += 64) a = fmaf(wr[(size_t)j * C + c], pl[c], a);
         a = wave_sum_f(a) + br[j];
         if (lane == 0) {
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(256) void se_train_fwd_kernel(const float* __restri
     for (int c = tid; c < C; c += 256) {
         float a = be[c];
         const float* w = we + (size_t)c * S;
+#pragma unroll 8
         for (int j = 0; j < S; ++j) a = fmaf(w[j], sq[j], a);
         e[(size_t)b * C + c] = a;
         gate[(size_t)b * C + c] = sigmoid_fast(a);
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(256) void se_train_bwd_image_kernel(const float* __
     __syncthreads();
     for (int j = wave; j < S; j += 4) {
         float a = 0.f;
+#pragma unroll 8
         for (int c = lane; c < C; c += 64) a = fmaf(we[(size_t)c * S + j], dl[c], a);
         a = wave_sum_f(a);
         if (lane == 0) {
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(256) void se_train_bwd_image_kernel(const float* __
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float a = 0.f;
+#pragma unroll 8
         for (int j = 0; j < S; ++j) a = fmaf(wr[(size_t)j * C + c], dr[j], a);
         dpooled[(size_t)b * C + c] = a;
     }

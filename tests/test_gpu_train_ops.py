@@ -14,17 +14,24 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-@pytest.mark.parametrize("M,K,N", [(240, 6756, 512), (12, 512, 1024), (64, 256, 2048), (7, 20, 36), (588, 1152, 192), (130, 100, 70)])
+@pytest.mark.parametrize("M,K,N", [(240, 6756, 512), (12, 512, 1024), (64, 256, 2048), (7, 20, 36), (588, 1152, 192), (130, 100, 70),
+                                   (12, 2048, 512), (5, 777, 6756), (16, 300, 4096), (3, 64, 20), (12, 6756, 512)])
 def test_gemm_nn(M, K, N):
     from image_captioning_amd import train_ops as T
     a, b = rnd(M, K, seed=1), rnd(K, N, seed=2) * K ** -0.5
+    want = a.double().mm(b.double()).float()
     got = T.gemm_nn(a.to(D), b.to(D)).cpu()
-    torch.testing.assert_close(got, a.double().mm(b.double()).float(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+    base = rnd(M, N, seed=15)
+    acc = base.to(D)
+    T.gemm_nn(a.to(D), b.to(D), out=acc, accumulate=True)
+    torch.testing.assert_close(acc.cpu(), base + want, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("K,M,N", [(240, 6756, 512), (150528, 96, 16), (12, 512, 1024), (3136, 144, 24), (37, 20, 36), (2352, 1152, 192),
                                    (40000, 24, 144), (33001, 36, 32), (50000, 240, 40), (65537, 17, 33), (40000, 144, 144),
-                                   (3001, 672, 112), (1000, 97, 49), (777, 130, 64), (2500, 480, 81), (515, 300, 1153)])
+                                   (3001, 672, 112), (1000, 97, 49), (777, 130, 64), (2500, 480, 81), (515, 300, 1153),
+                                   (12, 2048, 512), (12, 6756, 512), (5, 33, 64), (16, 512, 2048), (1, 1280, 512)])
 def test_gemm_tn(K, M, N):
     from image_captioning_amd import train_ops as T
     a, b = rnd(K, M, seed=3), rnd(K, N, seed=4) * K ** -0.5

@@ -118,6 +118,7 @@ SIGNATURES = {
     "icap_col_reduce_f32": (_i, [_i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
     "icap_col_reduce_ws_floats": (_ll, [_i, _i]),
     "icap_bn_finalize_f32": (_i, [_p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "icap_bn_train_stats_f32": (_i, [_p, _i, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "icap_bn_finalize_moments_f32": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "icap_scale_bias_act_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "icap_bn_act_bwd_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p]),

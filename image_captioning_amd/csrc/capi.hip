@@ -97,6 +97,8 @@ long long gemm_bwd_ws_floats(int, int, int, int);
 int col_reduce_f32(int, const float*, int, const float*, int, const float*, const float*, const float*, const float*, const float*,
                    const float*, int, int, int, float, int, float*, float*, float*, hipStream_t);
 long long col_reduce_ws_floats(int, int);
+int bn_train_stats_f32(const float*, int, const float*, const float*, float, float, int, int, float*, float*, float*, float*, float*,
+                       float*, float*, hipStream_t);
 int bn_finalize_moments_f32(const float*, const float*, const float*, const float*, const float*, float, float, int, int, float*,
                             float*, float*, float*, float*, float*, hipStream_t);
 int bn_finalize_f32(const float*, const float*, const float*, const float*, float, float, int, int, float*, float*, float*, float*,
@@ -612,6 +614,11 @@ int icap_col_reduce_f32(int mode, const float* a, int lda, const float* x, int l
     return col_reduce_f32(mode, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, scale, accumulate, out1, out2, ws, (hipStream_t)stream);
 }
 long long icap_col_reduce_ws_floats(int M, int C) { return col_reduce_ws_floats(M, C); }
+
+int icap_bn_train_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float momentum, int M, int C,
+                            float* mean, float* rstd, float* s, float* b, float* run_mean, float* run_var, float* ws, void* stream) {
+    return bn_train_stats_f32(x, ldx, gamma, beta, eps, momentum, M, C, mean, rstd, s, b, run_mean, run_var, ws, (hipStream_t)stream);
+}
 
 int icap_bn_finalize_moments_f32(const float* shift, const float* s1, const float* s2, const float* gamma, const float* beta,
                                  float eps, float momentum, int M, int C, float* mean, float* rstd, float* s, float* b,

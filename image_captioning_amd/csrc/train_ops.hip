@@ -237,6 +237,11 @@ static void col_launch_vec(int tx, dim3 grid, hipStream_t st, const float* a, in
     }
 }
 
+// first pass of a column reduction: per-chunk partial sums [planes][nchunks][C] into ws; returns the chunk count
+static int col_partial_dispatch(int mode, const float* a, int lda, const float* x, int ldx, const float* v1, const float* v2,
+                                const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C, float* ws,
+                                hipStream_t st);
+
 int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, const float* v1, const float* v2,
                    const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C, float scale,
                    int accumulate, float* out1, float* out2, float* ws, hipStream_t st) {
@@ -245,6 +250,14 @@ int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, c
     if (mode == COL_MOMENTS && !out2) { set_error("col_reduce: two outputs required"); return ICAP_ERR_ARG; }
     if (mode == COL_BN_BWD && (!x || !v1 || !v2 || !v3 || !v4 || !out2 || ldx < C)) { set_error("col_reduce: BatchNorm operands required"); return ICAP_ERR_ARG; }
     if (mode == COL_LN_BWD && (!x || !r1 || !r2 || !out2 || ldx < C)) { set_error("col_reduce: LayerNorm operands required"); return ICAP_ERR_ARG; }
+    const int nchunks = col_partial_dispatch(mode, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws, st);
+    hipLaunchKernelGGL(col_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, st, ws, nchunks, C, mode >= COL_BN_BWD ? 2 : 1, scale, accumulate, out1, out2);
+    return launch_status("col_reduce");
+}
+
+static int col_partial_dispatch(int mode, const float* a, int lda, const float* x, int ldx, const float* v1, const float* v2,
+                                const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C, float* ws,
+                                hipStream_t st) {
     const bool vec = (C % 4 == 0) && (lda % 4 == 0) && aligned16(a) && (!x || ((ldx % 4 == 0) && aligned16(x))) &&
                      (!v1 || aligned16(v1)) && (!v2 || aligned16(v2)) && (!v3 || aligned16(v3)) && (!v4 || aligned16(v4)) && aligned16(ws);
     int nchunks;
@@ -276,8 +289,7 @@ int col_reduce_f32(int mode, const float* a, int lda, const float* x, int ldx, c
             default: hipLaunchKernelGGL(col_partial_kernel<COL_LN_BWD>, grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, ws); break;
         }
     }
-    hipLaunchKernelGGL(col_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, st, ws, nchunks, C, mode >= COL_BN_BWD ? 2 : 1, scale, accumulate, out1, out2);
-    return launch_status("col_reduce");
+    return nchunks;
 }
 
 // ---------------------------------------------------------------- BatchNorm (training mode)
@@ -331,6 +343,69 @@ int bn_finalize_moments_f32(const float* shift, const float* s1, const float* s2
     if (!shift || !s1 || !s2 || !mean || !rstd || !s || !b || M <= 0 || C <= 0) { set_error("bn_finalize_moments: bad arguments"); return ICAP_ERR_ARG; }
     hipLaunchKernelGGL(bn_finalize_moments_kernel, dim3((C + 255) / 256), dim3(256), 0, st, shift, s1, s2, gamma, beta, eps, momentum, M, C, mean, rstd, s, b, run_mean, run_var);
     return launch_status("bn_finalize_moments");
+}
+
+// second pass of the one-pass statistics, fused with the finalisation: the chunk sums of both moment planes are added as in
+// col_finish_kernel (fixed order), then mean / rstd / fused scale and bias / running statistics are written - one launch less
+// per BatchNorm than col_reduce + bn_finalize_moments
+__global__ __launch_bounds__(256) void col_finish_bn_kernel(const float* __restrict__ part, int nchunks, const float* __restrict__ shift,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            float momentum, int M, int C, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, float* __restrict__ s, float* __restrict__ b,
+                                                            float* __restrict__ run_mean, float* __restrict__ run_var) {
+    __shared__ float red[32][8];
+    const int cx = threadIdx.x & 7, ky = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cx;
+    float tot[2] = {0.f, 0.f};
+    for (int pl = 0; pl < 2; ++pl) {
+        float acc = 0.f;
+        if (c < C) {
+            const float* src = part + (size_t)pl * nchunks * C + c;
+            for (int k0 = ky; k0 < nchunks; k0 += 32 * 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = k0 + 32 * u;
+                    v[u] = k < nchunks ? src[(size_t)k * C] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += v[u];
+            }
+        }
+        red[ky][cx] = acc;
+        __syncthreads();
+        if (ky == 0) {
+            float t = red[0][cx];
+#pragma unroll
+            for (int k = 1; k < 32; ++k) t += red[k][cx];
+            tot[pl] = t;
+        }
+        __syncthreads();
+    }
+    if (ky != 0 || c >= C) return;
+    const float a1 = tot[0];
+    const float mu = shift[c] + a1 / (float)M;
+    const float sq = fmaxf(tot[1] - a1 * a1 / (float)M, 0.f);
+    const float var = sq / (float)M;
+    const float r = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f;
+    mean[c] = mu;
+    rstd[c] = r;
+    s[c] = g * r;
+    b[c] = (beta ? beta[c] : 0.f) - mu * g * r;
+    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * (M > 1 ? sq / (float)(M - 1) : var);
+}
+
+// batch statistics of x [M][C] in one pass over x (moments about its first row) and everything a training-mode BatchNorm
+// derives from them; ws as for col_reduce_f32
+int bn_train_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float momentum, int M, int C,
+                       float* mean, float* rstd, float* s, float* b, float* run_mean, float* run_var, float* ws, hipStream_t st) {
+    if (!x || !mean || !rstd || !s || !b || !ws || M <= 0 || C <= 0 || ldx < C) { set_error("bn_train_stats: bad arguments"); return ICAP_ERR_ARG; }
+    const int nchunks = col_partial_dispatch(COL_MOMENTS, x, ldx, nullptr, 0, x, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE, M, C, ws, st);
+    hipLaunchKernelGGL(col_finish_bn_kernel, dim3((C + 7) / 8), dim3(256), 0, st, ws, nchunks, x, gamma, beta, eps, momentum, M, C, mean,
+                       rstd, s, b, run_mean, run_var);
+    return launch_status("bn_train_stats");
 }
 
 int bn_finalize_f32(const float* mean, const float* sqdev, const float* gamma, const float* beta, float eps, float momentum,

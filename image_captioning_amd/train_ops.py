@@ -116,14 +116,16 @@ def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NO
     _ckr(x, "x")
     M, C = x.shape
     dev = x.device
-    # one pass over x: moments about its first row (a sample of every column, so the subtraction stays benign)
-    shift = x[0]
-    s1, s2 = col_reduce(COL_MOMENTS, x, v1=shift)
+    # one pass over x: moments about its first row (a sample of every column, so the subtraction stays benign); the second
+    # pass of that reduction also derives mean / rstd / the fused scale and bias and updates the running statistics
     mean = torch.empty(C, device=dev); rstd = torch.empty(C, device=dev); s = torch.empty(C, device=dev); b = torch.empty(C, device=dev)
     lib = N.load()
-    N.check(lib.icap_bn_finalize_moments_f32(shift.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(gamma), _p(beta), float(eps),
-                                             float(momentum), M, C, mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), b.data_ptr(),
-                                             _p(run_mean), _p(run_var), _stream()), "bn_finalize_moments")
+    ws = _ws(lib.icap_col_reduce_ws_floats(M, C), dev)
+    span = _Span("col_reduce", (COL_MOMENTS, M, C))
+    N.check(lib.icap_bn_train_stats_f32(x.data_ptr(), x.stride(0), _p(gamma), _p(beta), float(eps), float(momentum), M, C,
+                                        mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), b.data_ptr(), _p(run_mean), _p(run_var),
+                                        ws.data_ptr(), _stream()), "bn_train_stats")
+    span.done()
     y = scale_bias_act(x, s, b, act=act, res=res, out=out)
     return y, (mean, rstd, s, b)
 

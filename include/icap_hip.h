@@ -462,6 +462,13 @@ int icap_bn_finalize_moments_f32(const float* shift, const float* s1, const floa
                                  float eps, float momentum, int M, int C, float* mean, float* rstd, float* s, float* b,
                                  float* run_mean, float* run_var, void* stream);
 
+/* Both steps in two launches instead of three: the one-pass moments of x [M][C] (rows ldx apart) about its first row, and -
+ * inside the reduction's second pass - mean, rstd, s, b and the running-statistics update.  ws: icap_col_reduce_ws_floats(M, C)
+ * floats.  This is what nn.BatchNorm2d / BatchNorm1d do with a batch in train() mode (transformer_word_level_bahdnau.py:12-25,
+ * 63-68 under model.train()). */
+int icap_bn_train_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float momentum, int M, int C,
+                            float* mean, float* rstd, float* s, float* b, float* run_mean, float* run_var, float* ws, void* stream);
+
 /* y = act(x * s[c] + b[c]) (+ res): normalisation + activation (+ identity skip) over [M][C]. */
 int icap_scale_bias_act_f32(const float* x, int ldx, const float* s, const float* b, const float* res, int ldr, int act,
                             int M, int C, float* y, int ldy, void* stream);

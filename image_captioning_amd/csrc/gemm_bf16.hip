@@ -322,19 +322,24 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                 for (int j = 0; j < RN; ++j)
                     bf[sp][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[sp * BPL + (buf * BN + wn * TN + j * 32 + lr) * LDK + koff]));
             }
+            if constexpr (SPLIT == 3) {
+                // smallest terms first: (a plane, b plane) pairs with plane sum <= 2.  Product-major order: consecutive MFMAs go
+                // to different accumulators, so none waits for the previous one's result
+                constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < RM; ++i)
+                for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int j = 0; j < RN; ++j) {
-                    if constexpr (SPLIT == 3) {   // smallest terms first; (a plane, b plane) pairs with plane sum <= 2
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
-                }
+                    for (int i = 0; i < RM; ++i)
+#pragma unroll
+                        for (int j = 0; j < RN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa[q]][i], bf[pb[q]][j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 

@@ -355,7 +355,9 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
             __syncthreads();
             if (t + 1 < nk) gload(t + 1, T0{});
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(2);      // the matrix-core phase outranks the other workgroup's staging arithmetic
             compute(0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }

@@ -302,6 +302,20 @@ def decode_b1(torch, dev):
         gbs = DECODE_PARAMS[name] * 4 / us / 1e3
         out[name] = {"us_per_step": us, "steps": steps, "captions_per_s": 1e3 / ms, "bytes_per_step": DECODE_PARAMS[name] * 4,
                      "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "mode": modes[name]}
+    # bf16 weight streaming (icap_greedy_*_w16_f32): the weight matrices are read as bf16 copies, everything else stays fp32
+    from image_captioning_amd import ops as _ops
+    _ops.set_decode_weights("bf16")
+    try:
+        for name, fn, steps in jobs[1:]:
+            ms = timeit(fn)
+            us = ms * 1e3 / steps
+            gbs = DECODE_PARAMS[name] * 2 / us / 1e3
+            out[name]["bf16_weights"] = {"us_per_step": us, "bytes_per_step": DECODE_PARAMS[name] * 2, "achieved_gbs": gbs,
+                                         "hbm_frac": gbs / HBM_PEAK_GBS, "speedup_vs_f32_weights": out[name]["us_per_step"] / us,
+                                         "tolerance": "logits within 2e-2 of max |logit|, ids equal outside twice the logit error "
+                                                      "(tests/test_gpu_decode_w16.py)"}
+    finally:
+        _ops.set_decode_weights(None)
     # the char model step by step, for comparison with its table path: the step-per-launch driver and the persistent launch
     for mode in ("steps", "persistent"):
         ms = timeit(lambda: cm.greedy_ids_from_features(f512, 58, mode=mode))

@@ -108,6 +108,9 @@ SIGNATURES = {
     "icap_greedy_tfm_persist_ws_bytes": (_ll, [_i] * 4),
     "icap_greedy_tfm_persist_f32": (_i, [C.POINTER(TfmWeights), _p, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_bah_f32": (_i, [C.POINTER(BahWeights), _p, _i, _p, _p, _p, _p, _i, _i, _p]),
+    "icap_greedy_rnn_w16_f32": (_i, [C.POINTER(RnnWeights), _p, _p, _p, _p, _i, _i, _p]),
+    "icap_greedy_tfm_w16_f32": (_i, [C.POINTER(TfmWeights), _p, _p, _p, _p, _p, _i, _i, _p]),
+    "icap_greedy_bah_w16_f32": (_i, [C.POINTER(BahWeights), _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_bah_ws_floats": (_ll, [_i] * 5),
     "icap_ce_loss_fwd_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _ll, _i, _p, _p, _p, _p]),
     "icap_ce_loss_bwd_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _ll, _p, _p, _p, _p, _i, _p]),

@@ -429,8 +429,8 @@ int icap_greedy_rnn_static_f32(const icap_rnn_weights* w, const float* x0, long 
     return icap_greedy_rnn_f32(w, x0, ids, logits_out, ws, NB, steps, stream);
 }
 
-int icap_greedy_rnn_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, float* ws, int NB,
-                        int steps, void* stream) {
+static int greedy_rnn_impl(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, float* ws, int NB,
+                           int steps, void* stream, bool w16) {
     if (!w || !x0 || !ids || !ws || NB <= 0 || steps <= 0) { set_error("greedy_rnn: bad arguments"); return ICAP_ERR_ARG; }
     if (w->layers <= 0 || w->layers > 4 || w->H <= 0 || w->I <= 0 || w->V <= 0 || !w->fc_w || !w->fc_b || !w->in_table) {
         set_error("greedy_rnn: bad weight descriptor");
@@ -459,15 +459,25 @@ int icap_greedy_rnn_f32(const icap_rnn_weights* w, const float* x0, long long* i
             const float* c_in = cbuf + (2LL * l + cur) * hsz;
             float* c_out = cbuf + (2LL * l + (cur ^ 1)) * hsz;
             ICAP_TRY(rnn_cell_step_f32(w->is_lstm != 0, w->w_ih[l], w->w_hh[l], w->b_ih[l], w->b_hh[l], in, h_in, c_in, h_out,
-                                       c_out, NB, in_w, H, st));
+                                       c_out, NB, in_w, H, st, w16));
             in = plain_input(h_out, H);
             in_w = H;
         }
         float* lo = logits_out ? logits_out + (size_t)t * NB * V : nullptr;
-        ICAP_TRY(gemv_step_f32(w->fc_w, nullptr, w->fc_b, in, lo, V, NB, V, H, ACT_NONE, pv, pi, st));
+        ICAP_TRY(gemv_step_f32(w->fc_w, nullptr, w->fc_b, in, lo, V, NB, V, H, ACT_NONE, pv, pi, st, w16));
         cur ^= 1;
     }
     return argmax_finalize_f32(pv, pi, P, ids + (steps - 1), steps, nullptr, nullptr, nullptr, 0, 0, NB, st);
+}
+
+int icap_greedy_rnn_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, float* ws, int NB,
+                        int steps, void* stream) {
+    return greedy_rnn_impl(w, x0, ids, logits_out, ws, NB, steps, stream, false);
+}
+
+int icap_greedy_rnn_w16_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, float* ws, int NB,
+                            int steps, void* stream) {
+    return greedy_rnn_impl(w, x0, ids, logits_out, ws, NB, steps, stream, true);
 }
 
 // ------------------------------------------------------------------ greedy: word / char transformer
@@ -477,8 +487,8 @@ long long icap_greedy_tfm_ws_floats(int NB, int E, int FF, int V) {
     return 2 * align4((long long)NB * E) + align4((long long)NB * FF) + 2 * align4((long long)NB * P);
 }
 
-int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
-                        float* logits_out, float* ws, int NB, int steps, void* stream) {
+static int greedy_tfm_impl(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
+                           float* logits_out, float* ws, int NB, int steps, void* stream, bool w16) {
     if (!w || !ca || !start_ids || !ids || !ws || NB <= 0 || steps <= 0) { set_error("greedy_tfm: bad arguments"); return ICAP_ERR_ARG; }
     if (w->E <= 0 || w->FF <= 0 || w->V <= 0 || !w->emb || !w->ln2_g || !w->ln2_b || !w->ln3_g || !w->ln3_b || !w->fc1_w ||
         !w->fc1_b || !w->fc2_w || !w->fc2_b || !w->out_w || !w->out_b) {
@@ -503,8 +513,8 @@ int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long l
         in1.ln_b = w->ln2_b;
         in1.x_out = x;
         in1.ld_xout = E;
-        ICAP_TRY(gemv_step_f32(w->fc1_w, nullptr, w->fc1_b, in1, h, FF, NB, FF, E, ACT_RELU, nullptr, nullptr, st));
-        ICAP_TRY(gemv_step_f32(w->fc2_w, nullptr, w->fc2_b, plain_input(h, FF), y, E, NB, E, FF, ACT_NONE, nullptr, nullptr, st));
+        ICAP_TRY(gemv_step_f32(w->fc1_w, nullptr, w->fc1_b, in1, h, FF, NB, FF, E, ACT_RELU, nullptr, nullptr, st, w16));
+        ICAP_TRY(gemv_step_f32(w->fc2_w, nullptr, w->fc2_b, plain_input(h, FF), y, E, NB, E, FF, ACT_NONE, nullptr, nullptr, st, w16));
         // logits = out(LN3(x + y))
         StepInput in3 = plain_input(y, E);
         in3.add = x;
@@ -512,9 +522,19 @@ int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long l
         in3.ln_g = w->ln3_g;
         in3.ln_b = w->ln3_b;
         float* lo = logits_out ? logits_out + (size_t)t * NB * V : nullptr;
-        ICAP_TRY(gemv_step_f32(w->out_w, nullptr, w->out_b, in3, lo, V, NB, V, E, ACT_NONE, pv, pi, st));
+        ICAP_TRY(gemv_step_f32(w->out_w, nullptr, w->out_b, in3, lo, V, NB, V, E, ACT_NONE, pv, pi, st, w16));
     }
     return argmax_finalize_f32(pv, pi, P, ids + (steps - 1), steps, nullptr, nullptr, nullptr, 0, 0, NB, st);
+}
+
+int icap_greedy_tfm_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
+                        float* logits_out, float* ws, int NB, int steps, void* stream) {
+    return greedy_tfm_impl(w, ca, start_ids, ids, logits_out, ws, NB, steps, stream, false);
+}
+
+int icap_greedy_tfm_w16_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
+                            float* logits_out, float* ws, int NB, int steps, void* stream) {
+    return greedy_tfm_impl(w, ca, start_ids, ids, logits_out, ws, NB, steps, stream, true);
 }
 
 int icap_table_walk(const long long* next, const long long* start, long long* ids, const float* logits_tab, int ldl,
@@ -538,8 +558,8 @@ long long icap_greedy_bah_ws_floats(int NB, int E, int ENC, int H, int V) {
     return 4 * align4((long long)NB * H) + 2 * align4((long long)NB * P);
 }
 
-int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
-                        long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream) {
+static int greedy_bah_impl(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
+                           long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream, bool w16) {
     if (!w || !context || !start_ids || !ids || !ws || NB <= 0 || steps <= 0 || ENC <= 0) { set_error("greedy_bah: bad arguments"); return ICAP_ERR_ARG; }
     if (w->E <= 0 || w->H <= 0 || w->V <= 0 || !w->emb || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh || !w->fc_w) {
         set_error("greedy_bah: bad weight descriptor");
@@ -547,6 +567,7 @@ int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC
     }
     if (NB > 8) { set_error("greedy_bah: NB=%d exceeds 8 captions per call", NB); return ICAP_ERR_LIMIT; }
     if ((w->E % 4) || (ENC % 4)) { set_error("greedy_bah: E and ENC must be multiples of 4"); return ICAP_ERR_ALIGN; }
+    if (w16 && ((w->E + ENC) % 8)) { set_error("greedy_bah: bf16 weight rows need E + ENC to be a multiple of 8"); return ICAP_ERR_ALIGN; }
     hipStream_t st = (hipStream_t)stream;
     const int E = w->E, H = w->H, V = w->V, I = E + ENC, P = gemv_blocks(V);
     const long long hsz = align4((long long)NB * H);
@@ -566,12 +587,22 @@ int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC
         StepInput in = token_input(pv, pi, P, t == 0 ? start_ids : nullptr, ids + (t - 1), steps, w->emb, E, V);
         in.tail = context;
         in.ld_tail = ENC;
-        ICAP_TRY(rnn_cell_step_f32(true, w->w_ih, w->w_hh, w->b_ih, w->b_hh, in, h_in, c_in, h_out, c_out, NB, I, H, st));
+        ICAP_TRY(rnn_cell_step_f32(true, w->w_ih, w->w_hh, w->b_ih, w->b_hh, in, h_in, c_in, h_out, c_out, NB, I, H, st, w16));
         float* lo = logits_out ? logits_out + (size_t)t * NB * V : nullptr;
-        ICAP_TRY(gemv_step_f32(w->fc_w, w->fc_scale, w->fc_bias, plain_input(h_out, H), lo, V, NB, V, H, ACT_NONE, pv, pi, st));
+        ICAP_TRY(gemv_step_f32(w->fc_w, w->fc_scale, w->fc_bias, plain_input(h_out, H), lo, V, NB, V, H, ACT_NONE, pv, pi, st, w16));
         cur ^= 1;
     }
     return argmax_finalize_f32(pv, pi, P, ids + (steps - 1), steps, nullptr, nullptr, nullptr, 0, 0, NB, st);
+}
+
+int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
+                        long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream) {
+    return greedy_bah_impl(w, context, ENC, start_ids, ids, logits_out, ws, NB, steps, stream, false);
+}
+
+int icap_greedy_bah_w16_f32(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
+                            long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream) {
+    return greedy_bah_impl(w, context, ENC, start_ids, ids, logits_out, ws, NB, steps, stream, true);
 }
 
 // ------------------------------------------------------------------ training step

@@ -238,15 +238,31 @@ __device__ __forceinline__ void row_load(float4 (&w)[IT], const float4* row, int
     for (int i = 0; i < IT; ++i) w[i] = row[min(k0 + i * stride, K4 - 1)];
 }
 
-template <int IT, int NB>
-__device__ __forceinline__ void row_dot(const float4 (&w)[IT], const float4* vec, int K4, int k0, int stride, float (&acc)[NB]) {
+// Dot products of one 16-byte weight segment per i with the staged vectors.  KU counts the row's 16-byte units:
+// K/4 for fp32 weights, K/8 for bf16 weights (W16: a unit holds eight weights, widened exactly by a 16-bit shift,
+// and meets two consecutive float4 of the vector); K4 = K/4 is the vectors' row pitch.
+template <int IT, int NB, bool W16>
+__device__ __forceinline__ void row_dot(const float4 (&w)[IT], const float4* vec, int K4, int KU, int k0, int stride, float (&acc)[NB]) {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int k4 = k0 + i * stride;
-        const float4 wv = f4_sel(k4 < K4, w[i]);
-        const int kc = min(k4, K4 - 1);
+        const int ku = k0 + i * stride;
+        const float4 wv = f4_sel(ku < KU, w[i]);
+        const int kc = min(ku, KU - 1);
+        if constexpr (!W16) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = dot4(wv, vec[b * K4 + kc], acc[b]);
+            for (int b = 0; b < NB; ++b) acc[b] = dot4(wv, vec[b * K4 + kc], acc[b]);
+        } else {
+            const unsigned u0 = __float_as_uint(wv.x), u1 = __float_as_uint(wv.y), u2 = __float_as_uint(wv.z), u3 = __float_as_uint(wv.w);
+            const float4 lo = make_float4(__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16),
+                                          __uint_as_float(u1 & 0xffff0000u));
+            const float4 hi = make_float4(__uint_as_float(u2 << 16), __uint_as_float(u2 & 0xffff0000u), __uint_as_float(u3 << 16),
+                                          __uint_as_float(u3 & 0xffff0000u));
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                acc[b] = dot4(lo, vec[b * K4 + 2 * kc], acc[b]);
+                acc[b] = dot4(hi, vec[b * K4 + 2 * kc + 1], acc[b]);
+            }
+        }
     }
 }
 
@@ -255,8 +271,8 @@ __device__ __forceinline__ void row_dot(const float4 (&w)[IT], const float4* vec
 // A workgroup of T/64 waves owns RB = R * (T/64) / KW rows; KW waves share a row's K range.
 // With part_val the workgroup also writes its best (value, index) per b to
 // part_val/part_idx[b][blockIdx.x]; y may then be null.
-template <int NB, int T, int R, int KW, int IT>
-__global__ __launch_bounds__(T) void gemv_kernel(const float* __restrict__ W, const float* __restrict__ scale,
+template <int NB, int T, int R, int KW, int IT, bool W16>
+__global__ __launch_bounds__(T) void gemv_kernel(const void* __restrict__ W, const float* __restrict__ scale,
                                                  const float* __restrict__ bias, const StepInput in, int nb,
                                                  float* __restrict__ y, int ldy, int N, int K, int act,
                                                  float* __restrict__ part_val, int* __restrict__ part_idx) {
@@ -268,17 +284,17 @@ __global__ __launch_bounds__(T) void gemv_kernel(const float* __restrict__ W, co
     __shared__ StageShared sh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave / KW, kp = wave % KW;
-    const int K4 = K >> 2;
+    const int K4 = K >> 2, KU = W16 ? K >> 3 : K4;  // 16-byte units of a weight row
     constexpr int stride = 64 * KW;
     const int k0 = kp * 64 + lane;
     const float4* W4 = reinterpret_cast<const float4*>(W);
     const float4* rows[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) rows[r] = W4 + (size_t)min(blockIdx.x * RB + wr * R + r, N - 1) * K4;
+    for (int r = 0; r < R; ++r) rows[r] = W4 + (size_t)min(blockIdx.x * RB + wr * R + r, N - 1) * KU;
 
     float4 wv[R][IT];
 #pragma unroll
-    for (int r = 0; r < R; ++r) row_load<IT>(wv[r], rows[r], K4, k0, stride);
+    for (int r = 0; r < R; ++r) row_load<IT>(wv[r], rows[r], KU, k0, stride);
     // epilogue operands of the threads that finish a (row, caption) pair, fetched up front
     const int er = tid / NB, eb = tid - er * NB;
     const int en = blockIdx.x * RB + er;
@@ -297,11 +313,11 @@ __global__ __launch_bounds__(T) void gemv_kernel(const float* __restrict__ W, co
         for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
     for (int base = 0;;) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) row_dot<IT, NB>(wv[r], xs, K4, base + k0, stride, acc[r]);
+        for (int r = 0; r < R; ++r) row_dot<IT, NB, W16>(wv[r], xs, K4, KU, base + k0, stride, acc[r]);
         base += IT * stride;
-        if (base >= K4) break;
+        if (base >= KU) break;
 #pragma unroll
-        for (int r = 0; r < R; ++r) row_load<IT>(wv[r], rows[r], K4, base + k0, stride);
+        for (int r = 0; r < R; ++r) row_load<IT>(wv[r], rows[r], KU, base + k0, stride);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -351,23 +367,37 @@ int gemv_blocks(int N) {
     return (N + rb - 1) / rb;
 }
 
-template <int NB, int T, int R, int KW>
-static void gemv_launch_it(int K4, int blocks, size_t lds, hipStream_t st, const float* W, const float* scale,
+template <int NB, int T, int R, int KW, bool W16>
+static void gemv_launch_it(int KU, int blocks, size_t lds, hipStream_t st, const void* W, const float* scale,
                            const float* bias, const StepInput& in, int nb, float* y, int ldy, int N, int K, int act,
                            float* pv, int* pi) {
-    if (K4 > 128 * KW)
-        hipLaunchKernelGGL((gemv_kernel<NB, T, R, KW, 4>), dim3(blocks), dim3(T), lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
+    if (KU > 128 * KW)
+        hipLaunchKernelGGL((gemv_kernel<NB, T, R, KW, 4, W16>), dim3(blocks), dim3(T), lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
+    else if (!W16 || KU > 64 * KW)
+        hipLaunchKernelGGL((gemv_kernel<NB, T, R, KW, 2, W16>), dim3(blocks), dim3(T), lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
     else
-        hipLaunchKernelGGL((gemv_kernel<NB, T, R, KW, 2>), dim3(blocks), dim3(T), lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
+        hipLaunchKernelGGL((gemv_kernel<NB, T, R, KW, 1, W16>), dim3(blocks), dim3(T), lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
 }
 
-template <int NB>
-static void gemv_launch(int rb, int K4, int blocks, size_t lds, hipStream_t st, const float* W, const float* scale,
+template <int NB, bool W16>
+static void gemv_launch(int rb, int KU, int blocks, size_t lds, hipStream_t st, const void* W, const float* scale,
                         const float* bias, const StepInput& in, int nb, float* y, int ldy, int N, int K, int act, float* pv,
                         int* pi) {
-    if (rb == 1) gemv_launch_it<NB, 256, 1, 4>(K4, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
-    else if (rb == 4) gemv_launch_it<NB, 256, 1, 1>(K4, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
-    else gemv_launch_it<NB, 256, 4, 1>(K4, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
+    if (rb == 1) gemv_launch_it<NB, 256, 1, 4, W16>(KU, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
+    else if (rb == 4) gemv_launch_it<NB, 256, 1, 1, W16>(KU, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
+    else gemv_launch_it<NB, 256, 4, 1, W16>(KU, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi);
+}
+
+template <bool W16>
+static void gemv_dispatch(int nbt, int rb, int KU, int blocks, size_t lds, hipStream_t st, const void* W, const float* scale,
+                          const float* bias, const StepInput& in, int nb, float* y, int ldy, int N, int K, int act, float* pv,
+                          int* pi) {
+    switch (nbt) {
+        case 1: gemv_launch<1, W16>(rb, KU, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi); break;
+        case 2: gemv_launch<2, W16>(rb, KU, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi); break;
+        case 4: gemv_launch<4, W16>(rb, KU, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi); break;
+        default: gemv_launch<8, W16>(rb, KU, blocks, lds, st, W, scale, bias, in, nb, y, ldy, N, K, act, pv, pi); break;
+    }
 }
 
 static int check_input(const char* what, const StepInput& in, int NB, int K) {
@@ -392,8 +422,9 @@ static int check_input(const char* what, const StepInput& in, int NB, int K) {
     return ICAP_OK;
 }
 
-int gemv_step_f32(const float* W, const float* scale, const float* bias, const StepInput& in, float* y, int ldy, int NB,
-                  int N, int K, int act, float* part_val, int* part_idx, hipStream_t st) {
+// w16: W holds bf16 weights (round to nearest even of the fp32 matrix, same [N][K] layout); products and sums stay fp32.
+int gemv_step_f32(const void* W, const float* scale, const float* bias, const StepInput& in, float* y, int ldy, int NB,
+                  int N, int K, int act, float* part_val, int* part_idx, hipStream_t st, bool w16) {
     const bool argmax = part_val != nullptr;
     if (!W || (!y && !argmax) || (argmax && !part_idx) || NB <= 0 || N <= 0 || K <= 0) {
         set_error("gemv: bad arguments");
@@ -401,24 +432,21 @@ int gemv_step_f32(const float* W, const float* scale, const float* bias, const S
     }
     if (NB > GEMV_MAX_NB) { set_error("gemv: batch %d exceeds %d (use the GEMM path)", NB, GEMV_MAX_NB); return ICAP_ERR_LIMIT; }
     if (K % 4 || !aligned16(W)) { set_error("gemv: K %% 4 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
+    if (w16 && K % 8) { set_error("gemv: bf16 weight rows need K=%d to be a multiple of 8", K); return ICAP_ERR_ALIGN; }
     const int rc = check_input("gemv", in, NB, K);
     if (rc != ICAP_OK) return rc;
     const int nbt = NB <= 1 ? 1 : (NB <= 2 ? 2 : (NB <= 4 ? 4 : 8));
     const size_t lds = (size_t)nbt * K * sizeof(float);
     if (lds > 96 * 1024) { set_error("gemv: NB*K=%d floats do not fit the LDS budget", nbt * K); return ICAP_ERR_LIMIT; }
-    const int rb = gemv_rows_per_block(N), blocks = gemv_blocks(N), K4 = K / 4;
-    switch (nbt) {
-        case 1: gemv_launch<1>(rb, K4, blocks, lds, st, W, scale, bias, in, NB, y, ldy, N, K, act, part_val, part_idx); break;
-        case 2: gemv_launch<2>(rb, K4, blocks, lds, st, W, scale, bias, in, NB, y, ldy, N, K, act, part_val, part_idx); break;
-        case 4: gemv_launch<4>(rb, K4, blocks, lds, st, W, scale, bias, in, NB, y, ldy, N, K, act, part_val, part_idx); break;
-        default: gemv_launch<8>(rb, K4, blocks, lds, st, W, scale, bias, in, NB, y, ldy, N, K, act, part_val, part_idx); break;
-    }
+    const int rb = gemv_rows_per_block(N), blocks = gemv_blocks(N);
+    if (w16) gemv_dispatch<true>(nbt, rb, K / 8, blocks, lds, st, W, scale, bias, in, NB, y, ldy, N, K, act, part_val, part_idx);
+    else gemv_dispatch<false>(nbt, rb, K / 4, blocks, lds, st, W, scale, bias, in, NB, y, ldy, N, K, act, part_val, part_idx);
     return launch_status("gemv");
 }
 
 int gemv_f32(const float* W, const float* scale, const float* bias, const float* x, int ldx, float* y, int ldy, int NB,
              int N, int K, int act, float* part_val, int* part_idx, hipStream_t st) {
-    return gemv_step_f32(W, scale, bias, plain_input(x, ldx), y, ldy, NB, N, K, act, part_val, part_idx, st);
+    return gemv_step_f32(W, scale, bias, plain_input(x, ldx), y, ldy, NB, N, K, act, part_val, part_idx, st, false);
 }
 
 // ---------------------------------------------------------------- arg-max finalize (+ next-token gather)
@@ -475,8 +503,8 @@ int argmax_finalize_f32(const float* part_val, const int* part_idx, int nparts, 
 //         (n = tanh(W_in x + b_in + r * (W_hn h + b_hn)) needs the two halves apart).
 // The gate pre-activations meet in LDS and lanes 0..nb-1 apply the cell update.
 // x comes from StepInput ([NB][I]); h_in/c_in/h_out/c_out are [NB][H].
-template <int NB, int IT, bool LSTM>
-__global__ __launch_bounds__(256) void rnn_cell_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+template <int NB, int IT, bool LSTM, bool W16>
+__global__ __launch_bounds__(256) void rnn_cell_kernel(const void* __restrict__ w_ih, const void* __restrict__ w_hh,
                                                        const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                        const StepInput in, int nb, const float* __restrict__ h_in,
                                                        const float* __restrict__ c_in, float* __restrict__ h_out,
@@ -486,17 +514,18 @@ __global__ __launch_bounds__(256) void rnn_cell_kernel(const float* __restrict__
     __shared__ StageShared sh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int I4 = I >> 2, H4 = H >> 2;
+    const int IU = W16 ? I >> 3 : I4, HU = W16 ? H >> 3 : H4;  // 16-byte units of a weight row
     const int j = blockIdx.x;
     float4* xs = vs;
     float4* hs = vs + NB * I4;
     const bool has_a = LSTM || wave < 3, has_b = LSTM || wave != 2;
     const int gate = LSTM ? wave : min(wave, 2);
-    const float4* row_a = reinterpret_cast<const float4*>(w_ih) + (size_t)(gate * H + j) * I4;
-    const float4* row_b = reinterpret_cast<const float4*>(w_hh) + (size_t)(gate * H + j) * H4;
+    const float4* row_a = reinterpret_cast<const float4*>(w_ih) + (size_t)(gate * H + j) * IU;
+    const float4* row_b = reinterpret_cast<const float4*>(w_hh) + (size_t)(gate * H + j) * HU;
     constexpr int stride = 64;
     float4 wa[IT], wb[IT];
-    if (has_a) row_load<IT>(wa, row_a, I4, lane, stride);
-    if (has_b) row_load<IT>(wb, row_b, H4, lane, stride);
+    if (has_a) row_load<IT>(wa, row_a, IU, lane, stride);
+    if (has_b) row_load<IT>(wb, row_b, HU, lane, stride);
     float4 hv[XU];
     vec_issue<256>(h_in, H, nb * H4, H4, hv);
     // operands of the cell update (threads 0..nb-1), fetched up front
@@ -526,18 +555,18 @@ __global__ __launch_bounds__(256) void rnn_cell_kernel(const float* __restrict__
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
     if (has_a) {
         for (int base = 0;;) {
-            row_dot<IT, NB>(wa, xs, I4, base + lane, stride, acc);
+            row_dot<IT, NB, W16>(wa, xs, I4, IU, base + lane, stride, acc);
             base += IT * stride;
-            if (base >= I4) break;
-            row_load<IT>(wa, row_a, I4, base + lane, stride);
+            if (base >= IU) break;
+            row_load<IT>(wa, row_a, IU, base + lane, stride);
         }
     }
     if (has_b) {
         for (int base = 0;;) {
-            row_dot<IT, NB>(wb, hs, H4, base + lane, stride, acc);
+            row_dot<IT, NB, W16>(wb, hs, H4, HU, base + lane, stride, acc);
             base += IT * stride;
-            if (base >= H4) break;
-            row_load<IT>(wb, row_b, H4, base + lane, stride);
+            if (base >= HU) break;
+            row_load<IT>(wb, row_b, HU, base + lane, stride);
         }
     }
     wave_sum_n<NB>(acc);
@@ -566,31 +595,34 @@ __global__ __launch_bounds__(256) void rnn_cell_kernel(const float* __restrict__
     }
 }
 
-template <int NB, bool LSTM>
-static void cell_launch(int it, int H, size_t lds, hipStream_t st, const float* w_ih, const float* w_hh, const float* b_ih,
+template <int NB, bool LSTM, bool W16>
+static void cell_launch(int it, int H, size_t lds, hipStream_t st, const void* w_ih, const void* w_hh, const float* b_ih,
                         const float* b_hh, const StepInput& in, int nb, const float* h_in, const float* c_in, float* h_out,
                         float* c_out, int I) {
     if (it > 2)
-        hipLaunchKernelGGL((rnn_cell_kernel<NB, 4, LSTM>), dim3(H), dim3(256), lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I, H);
+        hipLaunchKernelGGL((rnn_cell_kernel<NB, 4, LSTM, W16>), dim3(H), dim3(256), lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I, H);
+    else if (!W16 || it > 1)
+        hipLaunchKernelGGL((rnn_cell_kernel<NB, 2, LSTM, W16>), dim3(H), dim3(256), lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I, H);
     else
-        hipLaunchKernelGGL((rnn_cell_kernel<NB, 2, LSTM>), dim3(H), dim3(256), lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I, H);
+        hipLaunchKernelGGL((rnn_cell_kernel<NB, 1, LSTM, W16>), dim3(H), dim3(256), lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I, H);
 }
 
-template <bool LSTM>
-static void cell_dispatch(int nbt, int it, int H, size_t lds, hipStream_t st, const float* w_ih, const float* w_hh,
+template <bool LSTM, bool W16>
+static void cell_dispatch(int nbt, int it, int H, size_t lds, hipStream_t st, const void* w_ih, const void* w_hh,
                           const float* b_ih, const float* b_hh, const StepInput& in, int nb, const float* h_in,
                           const float* c_in, float* h_out, float* c_out, int I) {
     switch (nbt) {
-        case 1: cell_launch<1, LSTM>(it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I); break;
-        case 2: cell_launch<2, LSTM>(it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I); break;
-        case 4: cell_launch<4, LSTM>(it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I); break;
-        default: cell_launch<8, LSTM>(it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I); break;
+        case 1: cell_launch<1, LSTM, W16>(it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I); break;
+        case 2: cell_launch<2, LSTM, W16>(it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I); break;
+        case 4: cell_launch<4, LSTM, W16>(it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I); break;
+        default: cell_launch<8, LSTM, W16>(it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, nb, h_in, c_in, h_out, c_out, I); break;
     }
 }
 
-int rnn_cell_step_f32(bool lstm, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+// w16: w_ih / w_hh hold bf16 weights (same layout); biases, state and sums stay fp32.
+int rnn_cell_step_f32(bool lstm, const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh,
                       const StepInput& in, const float* h_in, const float* c_in, float* h_out, float* c_out, int NB, int I,
-                      int H, hipStream_t st) {
+                      int H, hipStream_t st, bool w16) {
     const char* what = lstm ? "lstm_cell" : "gru_cell";
     if (!w_ih || !w_hh || !b_ih || !b_hh || !h_in || !h_out || (lstm && (!c_in || !c_out)) || NB <= 0 || I <= 0 || H <= 0) {
         set_error("%s: bad arguments", what);
@@ -602,27 +634,31 @@ int rnn_cell_step_f32(bool lstm, const float* w_ih, const float* w_hh, const flo
         set_error("%s: I, H %% 4 and 16-byte alignment required", what);
         return ICAP_ERR_ALIGN;
     }
+    if (w16 && (I % 8 || H % 8)) { set_error("%s: bf16 weight rows need I=%d and H=%d to be multiples of 8", what, I, H); return ICAP_ERR_ALIGN; }
     const int rc = check_input(what, in, NB, I);
     if (rc != ICAP_OK) return rc;
     const int nbt = NB <= 1 ? 1 : (NB <= 2 ? 2 : (NB <= 4 ? 4 : 8));
     const size_t lds = (size_t)nbt * (I + H) * sizeof(float);
     if (lds > 96 * 1024) { set_error("%s: NB*(I+H) does not fit the LDS budget", what); return ICAP_ERR_LIMIT; }
-    const int it = ((I > H ? I : H) / 4 + 63) / 64;
-    if (lstm) cell_dispatch<true>(nbt, it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, NB, h_in, c_in, h_out, c_out, I);
-    else cell_dispatch<false>(nbt, it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, NB, h_in, c_in, h_out, c_out, I);
+    const int unit = w16 ? 8 : 4;
+    const int it = ((I > H ? I : H) / unit + 63) / 64;
+    if (lstm && w16) cell_dispatch<true, true>(nbt, it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, NB, h_in, c_in, h_out, c_out, I);
+    else if (lstm) cell_dispatch<true, false>(nbt, it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, NB, h_in, c_in, h_out, c_out, I);
+    else if (w16) cell_dispatch<false, true>(nbt, it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, NB, h_in, c_in, h_out, c_out, I);
+    else cell_dispatch<false, false>(nbt, it, H, lds, st, w_ih, w_hh, b_ih, b_hh, in, NB, h_in, c_in, h_out, c_out, I);
     return launch_status(what);
 }
 
 int lstm_cell_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* x, int ldx,
                   const float* h_in, const float* c_in, float* h_out, float* c_out, int NB, int I, int H, hipStream_t st) {
     if (!x) { set_error("lstm_cell: bad arguments"); return ICAP_ERR_ARG; }
-    return rnn_cell_step_f32(true, w_ih, w_hh, b_ih, b_hh, plain_input(x, ldx), h_in, c_in, h_out, c_out, NB, I, H, st);
+    return rnn_cell_step_f32(true, w_ih, w_hh, b_ih, b_hh, plain_input(x, ldx), h_in, c_in, h_out, c_out, NB, I, H, st, false);
 }
 
 int gru_cell_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* x, int ldx,
                  const float* h_in, float* h_out, int NB, int I, int H, hipStream_t st) {
     if (!x) { set_error("gru_cell: bad arguments"); return ICAP_ERR_ARG; }
-    return rnn_cell_step_f32(false, w_ih, w_hh, b_ih, b_hh, plain_input(x, ldx), h_in, nullptr, h_out, nullptr, NB, I, H, st);
+    return rnn_cell_step_f32(false, w_ih, w_hh, b_ih, b_hh, plain_input(x, ldx), h_in, nullptr, h_out, nullptr, NB, I, H, st, false);
 }
 
 }  // namespace icap

@@ -47,11 +47,13 @@ inline StepInput plain_input(const float* x, int ldx) {
     return s;
 }
 
-int gemv_step_f32(const float* W, const float* scale, const float* bias, const StepInput& in, float* y, int ldy, int NB,
-                  int N, int K, int act, float* part_val, int* part_idx, hipStream_t st);
-int rnn_cell_step_f32(bool lstm, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+// w16: the weight matrices are bf16 (icap_to_bf16_f32 of the fp32 ones, same row-major layout, K / I / H multiples of 8);
+// everything else - inputs, biases, accumulation, outputs - stays fp32.
+int gemv_step_f32(const void* W, const float* scale, const float* bias, const StepInput& in, float* y, int ldy, int NB,
+                  int N, int K, int act, float* part_val, int* part_idx, hipStream_t st, bool w16 = false);
+int rnn_cell_step_f32(bool lstm, const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh,
                       const StepInput& in, const float* h_in, const float* c_in, float* h_out, float* c_out, int NB, int I,
-                      int H, hipStream_t st);
+                      int H, hipStream_t st, bool w16 = false);
 int gemv_blocks(int N);
 int argmax_finalize_f32(const float* part_val, const int* part_idx, int nparts, long long* ids, int ids_stride,
                         const float* table, const float* add, float* next_x, int ldx, int E, int NB, hipStream_t st);

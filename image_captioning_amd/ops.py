@@ -821,10 +821,45 @@ def _ptr(t):
     return C.c_void_p(_ck(t, "weight"))
 
 
-def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, ids=None, logits=None, static_ws=False):
+# Small-batch decode streams every weight once per step, so its time follows the bytes.  "bf16": the step-per-launch
+# drivers read bf16 copies of the weight MATRICES (made once per weight version, kept in the model's weight dict) and
+# keep everything else - tables, biases, inputs, state, sums, logits - in fp32.  None: follow the compute dtype ("bf16"
+# compute mode streams bf16 weights, the fp32 modes fp32 ones).
+DECODE_WEIGHTS = None
+
+
+def set_decode_weights(name) -> None:
+    global DECODE_WEIGHTS
+    if name not in (None, "f32", "bf16"):
+        raise IcapError(f"set_decode_weights: unknown dtype {name!r}")
+    DECODE_WEIGHTS = name
+
+
+def decode_weights_bf16() -> bool:
+    return (DECODE_WEIGHTS or ("bf16" if COMPUTE_DTYPE == "bf16" else "f32")) == "bf16"
+
+
+def _w16(wd: dict, key: str, idx=None) -> int:
+    """Address of the bf16 copy of weight matrix wd[key] (or wd[key][idx]); the copy is made on first use and lives in wd,
+    which is rebuilt whenever the weights change."""
+    ck = key + "_w16" if idx is None else f"{key}_w16_{idx}"
+    t = wd.get(ck)
+    if t is None:
+        src = wd[key] if idx is None else wd[key][idx]
+        if src.shape[-1] % 8:
+            raise IcapError(f"bf16 weight streaming: {key} rows of {src.shape[-1]} are not a multiple of 8")
+        t = wd[ck] = to_bf16(src.contiguous())
+    return t.data_ptr()
+
+
+def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, ids=None, logits=None, static_ws=False, w16=None):
     """wd: dict with is_lstm, w_ih/w_hh/b_ih/b_hh lists, fc_w, fc_b, in_table.  x0 [NB, I].
     static_ws: the entry point whose workspace lives inside the library (nothing is allocated when `ids` - and `logits`
-    if wanted - are passed in); calls that overlap on one GPU share that workspace and must be serialised."""
+    if wanted - are passed in); calls that overlap on one GPU share that workspace and must be serialised.
+    w16: stream bf16 copies of the weight matrices (icap_greedy_rnn_w16_f32); None follows decode_weights_bf16()."""
+    w16 = decode_weights_bf16() if w16 is None else w16
+    if w16 and static_ws:
+        raise IcapError("greedy_rnn: the built-in-workspace entry point streams fp32 weights only")
     lib = N.load()
     NB, I = x0.shape
     L = len(wd["w_ih"])
@@ -833,9 +868,11 @@ def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, ids=No
     w = N.RnnWeights()
     w.layers, w.H, w.I, w.V, w.is_lstm = L, H, I, V, int(wd["is_lstm"])
     for l in range(L):
-        w.w_ih[l] = _ck(wd["w_ih"][l], "w_ih"); w.w_hh[l] = _ck(wd["w_hh"][l], "w_hh")
+        w.w_ih[l] = _w16(wd, "w_ih", l) if w16 else _ck(wd["w_ih"][l], "w_ih")
+        w.w_hh[l] = _w16(wd, "w_hh", l) if w16 else _ck(wd["w_hh"][l], "w_hh")
         w.b_ih[l] = _ck(wd["b_ih"][l], "b_ih"); w.b_hh[l] = _ck(wd["b_hh"][l], "b_hh")
-    w.fc_w, w.fc_b, w.in_table = _ck(wd["fc_w"], "fc_w"), _ck(wd["fc_b"], "fc_b"), _ck(wd["in_table"], "in_table")
+    w.fc_w = _w16(wd, "fc_w") if w16 else _ck(wd["fc_w"], "fc_w")
+    w.fc_b, w.in_table = _ck(wd["fc_b"], "fc_b"), _ck(wd["in_table"], "in_table")
     dev = x0.device
     if ids is None:
         ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
@@ -850,27 +887,30 @@ def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, ids=No
                                                NB, steps, _stream()), "greedy_rnn_static")
         return ids, logits
     ws = torch.empty(lib.icap_greedy_rnn_ws_floats(NB, L, H, I, V), device=dev, dtype=torch.float32)
-    N.check(lib.icap_greedy_rnn_f32(C.byref(w), _ck(x0, "x0"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"),
-                                    _ck(ws, "ws"), NB, steps, _stream()), "greedy_rnn")
+    fn = lib.icap_greedy_rnn_w16_f32 if w16 else lib.icap_greedy_rnn_f32
+    N.check(fn(C.byref(w), _ck(x0, "x0"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()),
+            "greedy_rnn")
     return ids, logits
 
 
-def greedy_tfm(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False):
+def greedy_tfm(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False, w16=None):
+    """w16: stream bf16 copies of fc1 / fc2 / output_fc (icap_greedy_tfm_w16_f32); None follows decode_weights_bf16()."""
     lib = N.load()
+    w16 = decode_weights_bf16() if w16 is None else w16
     NB, E = ca.shape
     FF = wd["fc1_w"].shape[0]
     V = wd["out_w"].shape[0]
     w = N.TfmWeights()
     w.E, w.FF, w.V = E, FF, V
     for k in ("emb", "ln2_g", "ln2_b", "ln3_g", "ln3_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "out_w", "out_b"):
-        setattr(w, k, _ck(wd[k], k))
+        setattr(w, k, _w16(wd, k) if w16 and k in ("fc1_w", "fc2_w", "out_w") else _ck(wd[k], k))
     dev = ca.device
     ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
     logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
     ws = torch.empty(lib.icap_greedy_tfm_ws_floats(NB, E, FF, V), device=dev, dtype=torch.float32)
-    N.check(lib.icap_greedy_tfm_f32(C.byref(w), _ck(ca, "ca"), _ck(start_ids, "start_ids", torch.int64),
-                                    _ck(ids, "ids", torch.int64), _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()),
-            "greedy_tfm")
+    fn = lib.icap_greedy_tfm_w16_f32 if w16 else lib.icap_greedy_tfm_f32
+    N.check(fn(C.byref(w), _ck(ca, "ca"), _ck(start_ids, "start_ids", torch.int64), _ck(ids, "ids", torch.int64),
+               _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()), "greedy_tfm")
     return ids, logits
 
 
@@ -913,20 +953,22 @@ def greedy_tfm_persist(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, step
     return ids, logits
 
 
-def greedy_bah(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False):
+def greedy_bah(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False, w16=None):
+    """w16: stream bf16 copies of the LSTMCell matrices and fc (icap_greedy_bah_w16_f32); None follows decode_weights_bf16()."""
     lib = N.load()
+    w16 = decode_weights_bf16() if w16 is None else w16
     NB, ENC = context.shape
     V, E = wd["emb"].shape
     H = wd["w_hh"].shape[1]
     w = N.BahWeights()
     w.E, w.H, w.V = E, H, V
     for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "fc_w", "fc_scale", "fc_bias"):
-        setattr(w, k, _ck(wd[k], k))
+        setattr(w, k, _w16(wd, k) if w16 and k in ("w_ih", "w_hh", "fc_w") else _ck(wd[k], k))
     dev = context.device
     ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
     logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
     ws = torch.empty(lib.icap_greedy_bah_ws_floats(NB, E, ENC, H, V), device=dev, dtype=torch.float32)
-    N.check(lib.icap_greedy_bah_f32(C.byref(w), _ck(context, "context"), ENC, _ck(start_ids, "start_ids", torch.int64),
-                                    _ck(ids, "ids", torch.int64), _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()),
-            "greedy_bah")
+    fn = lib.icap_greedy_bah_w16_f32 if w16 else lib.icap_greedy_bah_f32
+    N.check(fn(C.byref(w), _ck(context, "context"), ENC, _ck(start_ids, "start_ids", torch.int64), _ck(ids, "ids", torch.int64),
+               _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()), "greedy_bah")
     return ids, logits

@@ -391,6 +391,21 @@ int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC
                         long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream);
 long long icap_greedy_bah_ws_floats(int NB, int E, int ENC, int H, int V);
 
+/* The three step-per-launch drivers above with bf16 WEIGHT STREAMING: at 1..8 captions a step's time is the time to read
+ * every weight once (seq2seqbasic.py:79-80: the LSTM / GRU matrices and Linear(H, V); transformer_word_level.py:76-78: fc1,
+ * fc2, output_fc; transformer_word_level_bahdnau.py:136-139: LSTMCell and fc), so these variants read half the bytes.
+ * Same descriptor structs and workspaces, but the MATRIX members - w_ih[], w_hh[], fc_w (rnn); fc1_w, fc2_w, out_w (tfm);
+ * w_ih, w_hh, fc_w (bah) - point at bf16 copies (icap_to_bf16_f32 of the fp32 matrices: round to nearest even, same
+ * row-major layout; row lengths must be multiples of 8).  Embedding tables, in_table, biases, LayerNorm / BatchNorm
+ * parameters, inputs, state, accumulation and outputs stay fp32: the only difference from the fp32 drivers is one
+ * rounding of each weight to 8 significand bits.  Error 2 (alignment) when a row length is not a multiple of 8. */
+int icap_greedy_rnn_w16_f32(const icap_rnn_weights* w, const float* x0, long long* ids, float* logits_out, float* ws,
+                            int NB, int steps, void* stream);
+int icap_greedy_tfm_w16_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
+                            float* logits_out, float* ws, int NB, int steps, void* stream);
+int icap_greedy_bah_w16_f32(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
+                            long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream);
+
 /* ------------------------------------------------------------------ training step: losses and optimizer */
 
 /* Masked cross entropy over R rows of V logits.  Row r of the logits lives at

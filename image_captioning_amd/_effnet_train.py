@@ -41,9 +41,11 @@ def _w2d(conv):
     return w.reshape(w.shape[0], w.shape[1]).float().contiguous()
 
 
-def _bn_act(tape, z, bn, act):
+def _bn_act(tape, z, bn, act, parts=None):
+    """parts: the column statistics the kernel that produced z left behind (ops.StatParts), when it has them."""
     mom = bn.momentum if bn.momentum is not None else 0.1
-    y, saved = T.batchnorm_train(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, mom, act=act)
+    y, saved = T.batchnorm_train(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, mom, act=act,
+                                 parts=parts)
     bn.num_batches_tracked += 1
 
     def bwd(dy):
@@ -55,13 +57,14 @@ def _bn_act(tape, z, bn, act):
 
 
 def _conv1x1(tape, x, conv, need_dx=True):
+    """-> (z, column statistics of z for the BatchNorm that follows, backward closure)"""
     w = _w2d(conv)
-    z = ops.linear(x, w)
+    z, parts = ops.linear_stats(x, w)
 
     def bwd(dz):
         tape.grad(conv.weight, T.gemm_tn(dz, x))
         return T.gemm_nn(dz, w) if need_dx else None
-    return z, bwd
+    return z, parts, bwd
 
 
 def _mbconv(tape, blk, x, B, H, W, idx, masks):
@@ -72,15 +75,15 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
     bw = []                                  # layer closures of this block, forward order
     a0 = x
     if blk.expand != 1:
-        z0, f = _conv1x1(tape, x, blk._expand_conv); bw.append(f)
-        a0, f = _bn_act(tape, z0, blk._bn0, ACT_SWISH); bw.append(f)
+        z0, st0, f = _conv1x1(tape, x, blk._expand_conv); bw.append(f)
+        a0, f = _bn_act(tape, z0, blk._bn0, ACT_SWISH, st0); bw.append(f)
     lo, hi = same_pad(k, stride)
     dw_w = blk._depthwise_conv.weight.detach().view(mid, k * k).t().float().contiguous()   # [k*k, C]
-    z1, _ = ops.dwconv2d(a0.view(B, H, W, mid), dw_w, ks=k, stride=stride, pad=(lo, hi, lo, hi))
+    z1, st1 = ops.dwconv2d_stats(a0.view(B, H, W, mid), dw_w, ks=k, stride=stride, pad=(lo, hi, lo, hi))
     Ho, Wo = z1.shape[1], z1.shape[2]
     HW = Ho * Wo
     z1 = z1.view(B * HW, mid)
-    a1, bn1_bwd = _bn_act(tape, z1, blk._bn1, ACT_SWISH)
+    a1, bn1_bwd = _bn_act(tape, z1, blk._bn1, ACT_SWISH, st1)
     # squeeze-excite
     sq = blk._se_reduce.weight.shape[0]
     wr, br = _w2d(blk._se_reduce), blk._se_reduce.bias.detach().float().contiguous()
@@ -88,8 +91,8 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
     pooled = T.image_dot(a1, None, B, HW, mid, scale=1.0 / HW)
     r_pre, e, gate = T.se_train_fwd(pooled, wr, br, we, be)          # reduce FC + swish + expand FC + sigmoid in one launch
     a2 = T.chan_affine(a1, gate, None, 0.0, B, HW, mid)
-    z2, proj_bwd = _conv1x1(tape, a2, blk._project_conv)
-    y, bn2_bwd = _bn_act(tape, z2, blk._bn2, ACT_NONE)
+    z2, st2, proj_bwd = _conv1x1(tape, a2, blk._project_conv)
+    y, bn2_bwd = _bn_act(tape, z2, blk._bn2, ACT_NONE, st2)
     skip = stride == 1 and cin == cout
     dc_mask = None
     if skip:
@@ -139,10 +142,10 @@ class CnnTrain(torch.autograd.Function):
         x4 = ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)                       # [B, H, W, 4]
         lo, hi = same_pad(3, 2)
         w_stem = conv_weight_khwc(eff._conv_stem.weight.detach(), 4)
-        z = ops.conv2d(x4, w_stem, stride=2, pad=(lo, hi, lo, hi))
+        z, st_stem = ops.conv2d_stats(x4, w_stem, stride=2, pad=(lo, hi, lo, hi))
         Ho, Wo = z.shape[1], z.shape[2]
         z = z.view(B * Ho * Wo, 32)
-        a, bn0_bwd = _bn_act(tape, z, eff._bn0, ACT_SWISH)
+        a, bn0_bwd = _bn_act(tape, z, eff._bn0, ACT_SWISH, st_stem)
 
         def stem_bwd(da):
             dz = bn0_bwd(da)
@@ -155,8 +158,8 @@ class CnnTrain(torch.autograd.Function):
         for idx, blk in enumerate(eff._blocks):
             x, H2, W2 = _mbconv(tape, blk, x, B, H2, W2, idx, masks)
         HW = H2 * W2
-        zh, head_bwd = _conv1x1(tape, x, eff._conv_head)
-        ah, bn1_bwd = _bn_act(tape, zh, eff._bn1, ACT_SWISH)
+        zh, st_head, head_bwd = _conv1x1(tape, x, eff._conv_head)
+        ah, bn1_bwd = _bn_act(tape, zh, eff._bn1, ACT_SWISH, st_head)
         pooled = T.image_dot(ah, None, B, HW, 1280, scale=1.0 / HW)
         given = (masks or {}).get("cnn_drop") if masks is not None else None
         if given is not None:

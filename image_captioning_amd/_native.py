@@ -122,6 +122,12 @@ SIGNATURES = {
     "icap_col_reduce_ws_floats": (_ll, [_i, _i]),
     "icap_bn_finalize_f32": (_i, [_p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
     "icap_bn_train_stats_f32": (_i, [_p, _i, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "icap_conv2d_stats_max_parts": (_ll, [_ll]),
+    "icap_conv2d_stats_f32": (_i, [_p, _p, _p] + [_i] * 12 + [_p, _ll, _p, _p]),
+    "icap_linear_f32x3_stats_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _ll, _p, _p]),
+    "icap_dwconv2d_stats_f32": (_i, [_p, _p, _p] + [_i] * 10 + [_p, _p, _p]),
+    "icap_bn_stats_from_parts_ws_floats": (_ll, [_i, _i]),
+    "icap_bn_stats_from_parts_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "icap_bn_finalize_moments_f32": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "icap_scale_bias_act_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "icap_bn_act_bwd_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p]),

@@ -99,6 +99,14 @@ int col_reduce_f32(int, const float*, int, const float*, int, const float*, cons
 long long col_reduce_ws_floats(int, int);
 int bn_train_stats_f32(const float*, int, const float*, const float*, float, float, int, int, float*, float*, float*, float*, float*,
                        float*, float*, hipStream_t);
+long long conv_stats_max_parts(long long);
+int conv_igemm_stats_f32(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, float*, long long,
+                         int*, hipStream_t);
+int linear_f32x3_stats_f32(const float*, const unsigned short*, float*, int, int, int, int, float*, long long, int*, hipStream_t);
+int dwconv2d_stats_f32(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, float*, float*, hipStream_t);
+long long bn_stats_from_parts_ws_floats(int, int);
+int bn_stats_from_parts_f32(const float*, const float*, int, int, int, int, const float*, const float*, float, float, float*, float*,
+                            float*, float*, float*, float*, float*, hipStream_t);
 int bn_finalize_moments_f32(const float*, const float*, const float*, const float*, const float*, float, float, int, int, float*,
                             float*, float*, float*, float*, float*, hipStream_t);
 int bn_finalize_f32(const float*, const float*, const float*, const float*, float, float, int, int, float*, float*, float*, float*,
@@ -649,6 +657,33 @@ long long icap_col_reduce_ws_floats(int M, int C) { return col_reduce_ws_floats(
 int icap_bn_train_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float momentum, int M, int C,
                             float* mean, float* rstd, float* s, float* b, float* run_mean, float* run_var, float* ws, void* stream) {
     return bn_train_stats_f32(x, ldx, gamma, beta, eps, momentum, M, C, mean, rstd, s, b, run_mean, run_var, ws, (hipStream_t)stream);
+}
+
+long long icap_conv2d_stats_max_parts(long long M) { return conv_stats_max_parts(M); }
+
+int icap_conv2d_stats_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                          int pad_t, int pad_l, int Ho, int Wo, float* stat_part, long long part_floats, int* info, void* stream) {
+    return conv_igemm_stats_f32(x, w, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, stat_part, part_floats, info,
+                                (hipStream_t)stream);
+}
+
+int icap_linear_f32x3_stats_f32(const float* x, const unsigned short* w3, float* y, int M, int K, int N, int cfg, float* stat_part,
+                                long long part_floats, int* info, void* stream) {
+    return linear_f32x3_stats_f32(x, w3, y, M, K, N, cfg, stat_part, part_floats, info, (hipStream_t)stream);
+}
+
+int icap_dwconv2d_stats_f32(const float* x, const float* w, float* y, int B, int H, int W, int C, int KS, int stride, int pad_t,
+                            int pad_l, int Ho, int Wo, float* stat_part, float* stat_cnt, void* stream) {
+    return dwconv2d_stats_f32(x, w, y, B, H, W, C, KS, stride, pad_t, pad_l, Ho, Wo, stat_part, stat_cnt, (hipStream_t)stream);
+}
+
+long long icap_bn_stats_from_parts_ws_floats(int P, int C) { return bn_stats_from_parts_ws_floats(P, C); }
+
+int icap_bn_stats_from_parts_f32(const float* part, const float* cnt, int P, int rows_per_part, int M, int C, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* mean, float* rstd, float* s, float* b,
+                                 float* run_mean, float* run_var, float* ws, void* stream) {
+    return bn_stats_from_parts_f32(part, cnt, P, rows_per_part, M, C, gamma, beta, eps, momentum, mean, rstd, s, b, run_mean, run_var, ws,
+                                   (hipStream_t)stream);
 }
 
 int icap_bn_finalize_moments_f32(const float* shift, const float* s1, const float* s2, const float* gamma, const float* beta,

@@ -147,6 +147,35 @@ __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Running statistics of a set of values: count, sum, and squared deviations about the set's own mean.  stat_merge adds a
+// second set (Chan's update), so no squares of un-centred values are ever formed.
+struct ColStat { float n, s, q; };
+
+__device__ __forceinline__ void stat_merge(ColStat& a, float nb, float sb, float qb) {
+    if (nb <= 0.f) return;
+    if (a.n <= 0.f) { a.n = nb; a.s = sb; a.q = qb; return; }
+    const float n = a.n + nb;
+    const float d = sb / nb - a.s / a.n;
+    a.q = a.q + qb + d * d * (a.n * nb / n);
+    a.s += sb;
+    a.n = n;
+}
+
+// Column statistics in a GEMM epilogue (for the train-mode BatchNorm that follows the GEMM).  While a pass of the tile
+// sits in LDS every thread already walks its rows with four columns in registers; it accumulates the moments of those values
+// about `shift` - the pass's first row, a sample of every column, so the later subtraction stays benign - and
+// stat_from_shifted turns a column's totals over nrows rows into (sum, squared deviations about the mean).
+__device__ __forceinline__ void stat_acc4(float4& s1, float4& s2, float4 v, float4 shift) {
+    const float dx = v.x - shift.x, dy = v.y - shift.y, dz = v.z - shift.z, dw = v.w - shift.w;
+    s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+    s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+}
+
+__device__ __forceinline__ void stat_from_shifted(float nrows, float shift, float s1, float s2, float* sum, float* m2) {
+    *sum = fmaf(nrows, shift, s1);
+    *m2 = nrows > 0.f ? fmaxf(s2 - s1 * s1 / nrows, 0.f) : 0.f;
+}
+
 // Counter-based uniform in [0, 1): element idx of stream `seed` (a splitmix64 finaliser of seed + idx * golden ratio).
 __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long idx) {
     unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ULL;

@@ -46,6 +46,7 @@ struct ConvParams {
     int tiles_n, tiles_m, m_fast, nblk, vec_ok;
     float* amax_val;        // optional [M][tiles_n]: per-tile row maxima of the outputs (arg-max partials)
     int* amax_idx;          // their column indices
+    float* stat_part;       // optional [P][2][Cout]: column sum and squared deviations of every BM-row tile of the result
 };
 
 // Phase time stamps for the tuning probe under tools/ (compiled in only there): wave 0 of the first 64 workgroups,
@@ -444,6 +445,10 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
                     if (p.bias) bp[u] = p.bias[n + u];
                 }
         }
+        static_assert(KSPLIT * EP_R * EP_LD >= 2 * 4 * EP_RPI * BN4, "the epilogue tile image also holds the statistics scratch");
+        // stat_part: moments of this thread's rows (four columns) about the tile's first row, carried over the passes
+        float4 st_shift = make_float4(0.f, 0.f, 0.f, 0.f), st_s1 = st_shift, st_s2 = st_shift;
+        float my_shift = 0.f;
         dispatch_act(p.act, [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
 #pragma unroll
@@ -461,6 +466,17 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
                             }
                 }
                 __syncthreads();
+                if (pass == 0 && p.stat_part) {
+                    // the tile's first row (split-K planes added): a sample of every column to centre the moments on
+                    st_shift = *reinterpret_cast<const float4*>(&ep[en4 * 4]);
+                    if (tid < BN) my_shift = ep[tid];
+#pragma unroll
+                    for (int k2 = 1; k2 < KSPLIT; ++k2) {
+                        const float4 o2 = *reinterpret_cast<const float4*>(&ep[(k2 * EP_R) * EP_LD + en4 * 4]);
+                        st_shift.x += o2.x; st_shift.y += o2.y; st_shift.z += o2.z; st_shift.w += o2.w;
+                        if (tid < BN) my_shift += ep[(k2 * EP_R) * EP_LD + tid];
+                    }
+                }
                 for (int row = erow; row < EP_R && erow < EP_RPI; row += EP_RPI) {
                     const int m = em0 + r0 + row;
                     if constexpr (AMAX && VEC && (BN4 & (BN4 - 1)) == 0) {
@@ -503,6 +519,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
                         const float4 o = *reinterpret_cast<const float4*>(&ep[(k2 * EP_R + row) * EP_LD + en4 * 4]);
                         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     }
+                    if (p.stat_part) stat_acc4(st_s1, st_s2, v, st_shift);
                     v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
                     v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
                     const size_t o = (size_t)m * p.ldy + n;
@@ -521,6 +538,33 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
                                 if (p.residual) t2 += p.residual[o + u];
                                 p.y[o + u] = act_c<ACT>(t2);
                             }
+                    }
+                }
+                if (pass == NPASS - 1 && p.stat_part) {
+                    // column statistics of the result for the BatchNorm that follows: the row groups' shifted moments meet
+                    // in LDS (the tile image is dead once every thread has read its rows) and one thread per column adds
+                    // them in order
+                    __syncthreads();
+                    float4* sc = reinterpret_cast<float4*>(ep);                   // [EP_RPI][BN4][2]
+                    if (erow < EP_RPI) {
+                        sc[(erow * BN4 + en4) * 2] = st_s1;
+                        sc[(erow * BN4 + en4) * 2 + 1] = st_s2;
+                    }
+                    __syncthreads();
+                    if (tid < BN && en0 + tid < p.Cout) {
+                        const int q4 = tid >> 2, e = tid & 3;
+                        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                        for (int r = 0; r < EP_RPI; ++r) {
+                            a1 += reinterpret_cast<const float*>(&sc[(r * BN4 + q4) * 2])[e];
+                            a2 += reinterpret_cast<const float*>(&sc[(r * BN4 + q4) * 2 + 1])[e];
+                        }
+                        const float nrows = (float)min(BM, p.M - em0);
+                        float psum, pm2;
+                        stat_from_shifted(nrows, my_shift, a1, a2, &psum, &pm2);
+                        const size_t part = (size_t)em0 / BM;
+                        p.stat_part[(part * 2 + 0) * p.Cout + en0 + tid] = psum;
+                        p.stat_part[(part * 2 + 1) * p.Cout + en0 + tid] = pm2;
                     }
                 }
                 __syncthreads();   // the tile image is dead: the next pass / the next tile's slice 0 may overwrite it
@@ -687,7 +731,7 @@ static ConvParams make_params(const float* x, const float* w, const float* scale
                               const float* residual, const float* gate, float* y, int B, int H, int W, int Cin,
                               int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act) {
     ConvParams p{x, w, scale, bias, residual, gate, y, B, H, W, Cin, Cout, KH, KW,
-                 stride, pad_t, pad_l, Ho, Wo, act, B * Ho * Wo, KH * KW * Cin, Cout, 0, 0, 0, 0, 0, nullptr, nullptr};
+                 stride, pad_t, pad_l, Ho, Wo, act, B * Ho * Wo, KH * KW * Cin, Cout, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
     p.vec_ok = (Cout % 4 == 0) && aligned16(y) && (!residual || aligned16(residual)) &&
                (!scale || aligned16(scale)) && (!bias || aligned16(bias));
     return p;
@@ -796,6 +840,39 @@ int linear_argmax_f32(const float* x, const float* w, const float* scale, const 
     if (ksteps >= 4 && (ksteps & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 1, true, true>(p, st);
     if ((ksteps & 1) == 0) return launch_cfg<64, 64, 2, 2, 1, 1, true, 2, true>(p, st);
     return launch_cfg<64, 64, 2, 2, 1, 2, true, 1, true>(p, st);
+}
+
+// Plain convolution / Linear (no scale, bias, residual, gate or activation) whose epilogue also leaves the column statistics
+// of its result for a train-mode BatchNorm: stat_part [P][2][Cout] (sum, squared deviations), P = info[0] blocks of
+// info[1] = BM rows each (one per row tile), for the tile configuration conv_igemm_f32 would pick for the shape.  The caller sizes
+// stat_part for the worst case: conv_stats_max_parts(M) partials.
+long long conv_stats_max_parts(long long M) { return (M + 31) / 32 + 8; }
+
+int conv_igemm_stats_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                         int stride, int pad_t, int pad_l, int Ho, int Wo, float* stat_part, long long part_floats, int* info,
+                         hipStream_t st) {
+    const int rc = validate(x, w, nullptr, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo);
+    if (rc != ICAP_OK) return rc;
+    if (!stat_part || !info) { set_error("conv_igemm_stats: null statistics buffer"); return ICAP_ERR_ARG; }
+    ConvParams p = make_params(x, w, nullptr, nullptr, nullptr, nullptr, y, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, ACT_NONE);
+    if (!p.vec_ok) { set_error("conv_igemm_stats: Cout %% 4 == 0 and a 16-byte aligned y required"); return ICAP_ERR_ALIGN; }
+    int cfg = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        auto it = g_use_tuned ? g_tuned.find(ShapeKey(B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo)) : g_tuned.end();
+        if (it != g_tuned.end()) cfg = it->second;
+    }
+    if (cfg < 0) cfg = heuristic_cfg(p.M, Cout, p.K);
+    const int bm = kCfgs[cfg].bm, rows = bm;
+    const long long parts = (long long)(p.M + bm - 1) / bm;         // one block of statistics per row tile
+    if (parts * 2 * Cout > part_floats) {
+        set_error("conv_igemm_stats: %lld partials of %d columns need %lld floats, the buffer holds %lld", parts, Cout, parts * 2 * Cout, part_floats);
+        return ICAP_ERR_LIMIT;
+    }
+    info[0] = (int)parts;
+    info[1] = rows;
+    p.stat_part = stat_part;
+    return kCfgs[cfg].fn(p, st);
 }
 
 // One named tile configuration on this problem (parity tests run every configuration the tuner may pick; a

@@ -33,6 +33,7 @@ struct GemmBf16Params {
     int H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo, KHW;
     int y16, res16;         // y is stored / residual is read as bf16 [M][N] (activations kept in bf16 between layers)
     int m_fast;             // tile order inside an XCD's range: 1 = consecutive tiles share a W panel, 0 = an A panel
+    float* stat_part;       // optional [P][2][N]: column sum and squared deviations of every BM-row tile of the result
 };
 
 // Workgroups go to the 8 XCDs round-robin by blockIdx and every XCD has its own L2.  Mapped naively (tile = blockIdx), the
@@ -385,6 +386,10 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
         if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
         if (p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + n);
     }
+    static_assert(EP_ROWS * EP_LD >= 2 * 4 * EP_RPI * BN4, "the epilogue tile image also holds the statistics scratch");
+    // stat_part: moments of this thread's rows (four columns) about the tile's first row, carried over the passes
+    float4 st_shift = make_float4(0.f, 0.f, 0.f, 0.f), st_s1 = st_shift, st_s2 = st_shift;
+    float my_shift = 0.f;
     dispatch_act(p.act, [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
 #pragma unroll
@@ -402,6 +407,10 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                         }
             }
             __syncthreads();
+            if (pass == 0 && p.stat_part) {
+                st_shift = *reinterpret_cast<const float4*>(&ep[en4 * 4]);        // the tile's first row: a sample of every column
+                if (tid < BN) my_shift = ep[tid];
+            }
             for (int row = erow; row < EP_ROWS; row += EP_RPI) {
                 const int m = m0 + r0 + row;
                 if constexpr (AMAX) {
@@ -431,6 +440,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                 }
                 if (m >= p.M || n >= p.N) continue;
                 float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
+                if (p.stat_part) stat_acc4(st_s1, st_s2, v, st_shift);
                 v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
                 v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
                 const size_t o = (size_t)m * p.N + n;
@@ -447,6 +457,29 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                 v.x = act_c<ACT>(v.x); v.y = act_c<ACT>(v.y); v.z = act_c<ACT>(v.z); v.w = act_c<ACT>(v.w);
                 if (p.y16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + o) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
                 else *reinterpret_cast<float4*>(p.y + o) = v;
+            }
+            if (pass == NPASS - 1 && p.stat_part) {
+                // column statistics of the result for the BatchNorm that follows: the row groups' shifted moments meet in
+                // LDS (the tile image is dead once every thread has read its rows) and one thread per column adds them in order
+                __syncthreads();
+                float4* sc = reinterpret_cast<float4*>(ep);                       // [EP_RPI][BN4][2]
+                sc[(erow * BN4 + en4) * 2] = st_s1;
+                sc[(erow * BN4 + en4) * 2 + 1] = st_s2;
+                __syncthreads();
+                if (tid < BN && n0 + tid < p.N) {
+                    const int q4 = tid >> 2, e = tid & 3;
+                    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < EP_RPI; ++r) {
+                        a1 += reinterpret_cast<const float*>(&sc[(r * BN4 + q4) * 2])[e];
+                        a2 += reinterpret_cast<const float*>(&sc[(r * BN4 + q4) * 2 + 1])[e];
+                    }
+                    const float nrows = (float)min(BM, p.M - m0);
+                    float psum, pm2;
+                    stat_from_shifted(nrows, my_shift, a1, a2, &psum, &pm2);
+                    p.stat_part[((size_t)tile_m * 2 + 0) * p.N + n0 + tid] = psum;
+                    p.stat_part[((size_t)tile_m * 2 + 1) * p.N + n0 + tid] = pm2;
+                }
             }
             __syncthreads();
         }
@@ -649,6 +682,37 @@ int linear_f32x3_f32(const float* x, int x_split, const unsigned short* w3, cons
         case 1: return gate ? gb16_split_launch<64, 128, true, false>(p, st) : gb16_split_launch<64, 128, false, false>(p, st);
         case 2: return gate ? gb16_split_launch<64, 64, true, false>(p, st) : gb16_split_launch<64, 64, false, false>(p, st);
         default: set_error("linear_f32x3: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
+    }
+}
+
+// Plain split-product Linear (no scale, bias, residual, gate or activation) whose epilogue also leaves the column statistics
+// of its result for a train-mode BatchNorm: stat_part [P][2][N] (sum, squared deviations), P = info[0] blocks of info[1] rows
+// each (one per row tile).  cfg as in linear_f32x3_f32.
+int linear_f32x3_stats_f32(const float* x, const unsigned short* w3, float* y, int M, int K, int N, int cfg, float* stat_part,
+                           long long part_floats, int* info, hipStream_t st) {
+    if (!y || !stat_part || !info) { set_error("linear_f32x3_stats: bad arguments"); return ICAP_ERR_ARG; }
+    const int rc = split_args_ok("linear_f32x3_stats", x, w3, nullptr, nullptr, nullptr, nullptr, y, M, K, N);
+    if (rc != ICAP_OK) return rc;
+    GemmBf16Params p{x, w3, nullptr, nullptr, nullptr, nullptr, y, M, N, K, 1, ACT_NONE, 0, nullptr, nullptr};
+    if (cfg < 0) {
+        const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+        const int waste = (N + 127) / 128 * 128 - N;
+        cfg = (t128 >= 192 && waste * 4 <= N) ? 0 : ((long long)((M + 63) / 64) * ((N + 127) / 128) >= 192 && waste * 4 <= N ? 1 : 2);
+    }
+    if (cfg < 0 || cfg > 2) { set_error("linear_f32x3_stats: unknown tile configuration %d", cfg); return ICAP_ERR_ARG; }
+    const int bm = cfg == 0 ? 128 : 64;
+    const long long parts = (long long)(M + bm - 1) / bm;            // one block of statistics per row tile
+    if (parts * 2 * N > part_floats) {
+        set_error("linear_f32x3_stats: %lld partials of %d columns need %lld floats, the buffer holds %lld", parts, N, parts * 2 * N, part_floats);
+        return ICAP_ERR_LIMIT;
+    }
+    info[0] = (int)parts;
+    info[1] = bm;
+    p.stat_part = stat_part;
+    switch (cfg) {
+        case 0: return gb16_split_launch<128, 128, false, false>(p, st);
+        case 1: return gb16_split_launch<64, 128, false, false>(p, st);
+        default: return gb16_split_launch<64, 64, false, false>(p, st);
     }
 }
 

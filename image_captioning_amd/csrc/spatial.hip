@@ -57,7 +57,8 @@ template <int KS, int S, int TH>
 __global__ __launch_bounds__(512) void dwconv_strip_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
     const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ partial, int H, int W,
-    int C, int pad_t, int pad_l, int Ho, int Wo, int act, int nq, int spb, int nstrips_w) {
+    int C, int pad_t, int pad_l, int Ho, int Wo, int act, int nq, int spb, int nstrips_w,
+    float* __restrict__ stat_part = nullptr, float* __restrict__ stat_cnt = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];
     constexpr int TW = DW_TW;
     constexpr int NIN = (TW - 1) * S + KS;     // input columns feeding one strip
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(512) void dwconv_strip_kernel(
     const int nstrips = ((Ho + TH - 1) / TH) * nstrips_w;
     const bool active = (ls < spb) && (strip < nstrips);
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);    // stat_part: squared deviations of this thread's outputs about their mean
+    float nvalid = 0.f;
     if (active) {
         const int c = cq << 2;
         const int hs = strip / nstrips_w;
@@ -133,10 +136,48 @@ __global__ __launch_bounds__(512) void dwconv_strip_kernel(
                         u.z = act_c<ACT>(fmaf(acc[t][o].z, sc.z, bi.z)); u.w = act_c<ACT>(fmaf(acc[t][o].w, sc.w, bi.w));
                         *reinterpret_cast<float4*>(yr + (size_t)wo * C) = u;
                         sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
+                        acc[t][o] = u;
+                        nvalid += 1.f;
                     }
                 }
             }
         });
+        if (stat_part && nvalid > 0.f) {
+            const float inv = 1.f / nvalid;
+            const float4 mu = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int o = 0; o < TW; ++o)
+                    if (ho0 + t < Ho && wo0 + o < Wo) {
+                        const float dx = acc[t][o].x - mu.x, dy = acc[t][o].y - mu.y, dz = acc[t][o].z - mu.z, dw = acc[t][o].w - mu.w;
+                        sq.x = fmaf(dx, dx, sq.x); sq.y = fmaf(dy, dy, sq.y); sq.z = fmaf(dz, dz, sq.z); sq.w = fmaf(dw, dw, sq.w);
+                    }
+        }
+    }
+    if (stat_part) {
+        // per-workgroup statistics of the outputs for a train-mode BatchNorm: the strips of a channel quad are merged in
+        // strip order; red holds [sum | squared deviations | count] per thread
+        float4* redq = red + blockDim.x;
+        float* redn = reinterpret_cast<float*>(red + 2 * blockDim.x);
+        red[tid] = sum;
+        redq[tid] = sq;
+        redn[tid] = nvalid;
+        __syncthreads();
+        if (tid < nq) {
+            ColStat a[4] = {{nvalid, sum.x, sq.x}, {nvalid, sum.y, sq.y}, {nvalid, sum.z, sq.z}, {nvalid, sum.w, sq.w}};
+            for (int l = 1; l < spb; ++l) {
+                const float4 so = red[l * nq + tid], qo = redq[l * nq + tid];
+                const float no = redn[l * nq + tid];
+                stat_merge(a[0], no, so.x, qo.x); stat_merge(a[1], no, so.y, qo.y);
+                stat_merge(a[2], no, so.z, qo.z); stat_merge(a[3], no, so.w, qo.w);
+            }
+            const size_t pidx = (size_t)b * gridDim.x + blockIdx.x;
+            *reinterpret_cast<float4*>(stat_part + (pidx * 2 + 0) * C + (tid << 2)) = make_float4(a[0].s, a[1].s, a[2].s, a[3].s);
+            *reinterpret_cast<float4*>(stat_part + (pidx * 2 + 1) * C + (tid << 2)) = make_float4(a[0].q, a[1].q, a[2].q, a[3].q);
+            if (tid == 0) stat_cnt[pidx] = a[0].n;
+        }
+        return;
     }
     if (partial) {
         red[tid] = sum;
@@ -184,9 +225,9 @@ int dwconv_chunks(int Ho, int Wo, int C, int KS, int stride) {
     return nblk;
 }
 
-int dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y,
-                 float* partial, int B, int H, int W, int C, int KS, int stride, int pad_t, int pad_l,
-                 int Ho, int Wo, int act, hipStream_t st) {
+static int dwconv2d_launch(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                           float* partial, int B, int H, int W, int C, int KS, int stride, int pad_t, int pad_l,
+                           int Ho, int Wo, int act, float* stat_part, float* stat_cnt, hipStream_t st) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || stride <= 0 || Ho <= 0 || Wo <= 0) {
         set_error("dwconv2d: bad arguments");
         return ICAP_ERR_ARG;
@@ -204,11 +245,11 @@ int dwconv2d_f32(const float* x, const float* w, const float* scale, const float
     dwconv_geometry(Ho, Wo, C, th, &bd, &spb, &nblk);
     const int nq = C / 4, nsw = (Wo + DW_TW - 1) / DW_TW;
     const dim3 grid(nblk, B), block(bd);
-    const size_t lds = partial ? (size_t)bd * sizeof(float4) : 0;
+    const size_t lds = stat_part ? (size_t)bd * (2 * sizeof(float4) + sizeof(float)) : (partial ? (size_t)bd * sizeof(float4) : 0);
 #define ICAP_DW(K_, S_)                                                                                                   \
     do {                                                                                                                 \
-        if (th == 2) hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 2>), grid, block, lds, st, x, w, scale, bias, y, partial, H, W, C, pad_t, pad_l, Ho, Wo, act, nq, spb, nsw); \
-        else hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 1>), grid, block, lds, st, x, w, scale, bias, y, partial, H, W, C, pad_t, pad_l, Ho, Wo, act, nq, spb, nsw); \
+        if (th == 2) hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 2>), grid, block, lds, st, x, w, scale, bias, y, partial, H, W, C, pad_t, pad_l, Ho, Wo, act, nq, spb, nsw, stat_part, stat_cnt); \
+        else hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 1>), grid, block, lds, st, x, w, scale, bias, y, partial, H, W, C, pad_t, pad_l, Ho, Wo, act, nq, spb, nsw, stat_part, stat_cnt); \
     } while (0)
     if (KS == 3 && stride == 1) ICAP_DW(3, 1);
     else if (KS == 3 && stride == 2) ICAP_DW(3, 2);
@@ -217,6 +258,21 @@ int dwconv2d_f32(const float* x, const float* w, const float* scale, const float
     else { set_error("dwconv2d: kernel %d stride %d not supported (3 or 5, stride 1 or 2)", KS, stride); return ICAP_ERR_ARG; }
 #undef ICAP_DW
     return launch_status("dwconv2d");
+}
+
+int dwconv2d_f32(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                 float* partial, int B, int H, int W, int C, int KS, int stride, int pad_t, int pad_l,
+                 int Ho, int Wo, int act, hipStream_t st) {
+    return dwconv2d_launch(x, w, scale, bias, y, partial, B, H, W, C, KS, stride, pad_t, pad_l, Ho, Wo, act, nullptr, nullptr, st);
+}
+
+// Plain depthwise convolution that also leaves the per-workgroup statistics of its result for a train-mode BatchNorm:
+// stat_part [P][2][C] (sum, squared deviations about the workgroup's own mean) and stat_cnt [P] (outputs per channel in the
+// workgroup), P = B * dwconv_chunks(Ho, Wo, C, KS, stride).
+int dwconv2d_stats_f32(const float* x, const float* w, float* y, int B, int H, int W, int C, int KS, int stride, int pad_t,
+                       int pad_l, int Ho, int Wo, float* stat_part, float* stat_cnt, hipStream_t st) {
+    if (!stat_part || !stat_cnt || !aligned16(stat_part)) { set_error("dwconv2d_stats: null or unaligned statistics buffers"); return ICAP_ERR_ARG; }
+    return dwconv2d_launch(x, w, nullptr, nullptr, y, nullptr, B, H, W, C, KS, stride, pad_t, pad_l, Ho, Wo, ACT_NONE, stat_part, stat_cnt, st);
 }
 
 // ---------------------------------------------------------------- squeeze-excite gate

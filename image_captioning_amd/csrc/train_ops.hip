@@ -408,6 +408,134 @@ int bn_train_stats_f32(const float* x, int ldx, const float* gamma, const float*
     return launch_status("bn_train_stats");
 }
 
+// ---- train-mode BatchNorm statistics from the partials the PRODUCING kernel left behind (the GEMM epilogues'
+// tile_col_stats, the depthwise kernel's per-workgroup sums): part [P][2][C] holds, per block of rows, every column's sum
+// and its squared deviations about the block's own mean; cnt [P] the block's row count (null: block p covers
+// min(rows_per_part, M - p * rows_per_part) rows).  Blocks are merged pairwise with Chan's update
+//   n = na + nb,  d = sb / nb - sa / na,  q = qa + qb + d^2 na nb / n
+// in a fixed order (a thread walks its partials in index order, the four row slots of a workgroup and then the chunks are
+// merged in index order), so the result does not depend on scheduling and no squares of un-centred values are ever formed.
+constexpr int STAT_U = 8;   // partials a thread keeps in flight
+
+// A workgroup = 64 columns x 4 row slots.  Slot k walks entries e0 + k, e0 + k + 4, ... of [e0, e1) with STAT_U loads in
+// flight, then the four slots are merged in order; slot 0 returns the column's statistics.  TRIPLE: entries are
+// (n, sum, q) triples [k][3][C] (the chunk results); otherwise raw partials [p][2][C] with their row counts.
+template <bool TRIPLE>
+__device__ __forceinline__ ColStat stat_walk(const float* __restrict__ src, const float* __restrict__ cnt, int e0, int e1,
+                                             int rows_per_part, int M, int C, int c, float (*red)[3][64]) {
+    const int cx = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    ColStat a = {0.f, 0.f, 0.f};
+    if (c < C) {
+        for (int eb = e0 + slot; eb < e1; eb += 4 * STAT_U) {
+            float sv[STAT_U], qv[STAT_U], nv[STAT_U];
+#pragma unroll
+            for (int u = 0; u < STAT_U; ++u) {
+                const int ee = eb + 4 * u;
+                const int ec = min(ee, e1 - 1);
+                float n_here;
+                if constexpr (TRIPLE) {
+                    n_here = src[((size_t)ec * 3 + 0) * C + c];
+                    sv[u] = src[((size_t)ec * 3 + 1) * C + c];
+                    qv[u] = src[((size_t)ec * 3 + 2) * C + c];
+                } else {
+                    sv[u] = src[((size_t)ec * 2 + 0) * C + c];
+                    qv[u] = src[((size_t)ec * 2 + 1) * C + c];
+                    n_here = cnt ? cnt[ec] : (float)min(rows_per_part, max(M - ec * rows_per_part, 0));
+                }
+                nv[u] = ee < e1 ? n_here : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < STAT_U; ++u) stat_merge(a, nv[u], sv[u], qv[u]);
+        }
+    }
+    red[slot][0][cx] = a.n; red[slot][1][cx] = a.s; red[slot][2][cx] = a.q;
+    __syncthreads();
+    if (slot == 0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) stat_merge(a, red[k][0][cx], red[k][1][cx], red[k][2][cx]);
+    }
+    return a;
+}
+
+// level 1: workgroup (column block of 64, chunk of ppc partials) -> chunk_out [nchunk][3][C] = (n, sum, q)
+__global__ __launch_bounds__(256) void stat_chunk_kernel(const float* __restrict__ part, const float* __restrict__ cnt, int P, int ppc,
+                                                         int rows_per_part, int M, int C, float* __restrict__ chunk_out) {
+    __shared__ float red[4][3][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int p0 = blockIdx.y * ppc, p1 = min(P, p0 + ppc);
+    const ColStat a = stat_walk<false>(part, cnt, p0, p1, rows_per_part, M, C, c, red);
+    if ((threadIdx.x >> 6) == 0 && c < C) {
+        float* o = chunk_out + (size_t)blockIdx.y * 3 * C;
+        o[c] = a.n; o[C + c] = a.s; o[2 * C + c] = a.q;
+    }
+}
+
+// level 2: merge the chunks (TRIPLE) - or, for a few hundred partials, the partials themselves in one launch - and derive
+// what the BatchNorm forward / backward need; updates the running statistics
+template <bool TRIPLE>
+__global__ __launch_bounds__(256) void stat_finish_bn_kernel(const float* __restrict__ src, const float* __restrict__ cnt, int nent,
+                                                             int rows_per_part, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float momentum, int M, int C,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ s,
+                                                             float* __restrict__ b, float* __restrict__ run_mean, float* __restrict__ run_var) {
+    __shared__ float red[4][3][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const ColStat a = stat_walk<TRIPLE>(src, cnt, 0, nent, rows_per_part, M, C, c, red);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    const float mu = a.n > 0.f ? a.s / a.n : 0.f;
+    const float sq = fmaxf(a.q, 0.f);
+    const float var = sq / (float)M;
+    const float r = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f;
+    mean[c] = mu;
+    rstd[c] = r;
+    s[c] = g * r;
+    b[c] = (beta ? beta[c] : 0.f) - mu * g * r;
+    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * (M > 1 ? sq / (float)(M - 1) : var);
+}
+
+// chunks of 32 partials (one round of loads per thread), doubled until at most 256 chunks are left for the second level
+constexpr int STAT_ONE_LAUNCH = 512;   // up to this many partials the finishing kernel reads them itself
+
+static void stat_geometry(int P, int* nchunk, int* ppc) {
+    int per = 32;
+    while ((P + per - 1) / per > 256) per *= 2;
+    *ppc = per;
+    *nchunk = (P + per - 1) / per;
+}
+
+long long bn_stats_from_parts_ws_floats(int P, int C) {
+    if (P <= 0 || C <= 0) return 0;
+    int nc, ppc;
+    stat_geometry(P, &nc, &ppc);
+    return 3LL * nc * C;
+}
+
+int bn_stats_from_parts_f32(const float* part, const float* cnt, int P, int rows_per_part, int M, int C, const float* gamma,
+                            const float* beta, float eps, float momentum, float* mean, float* rstd, float* s, float* b,
+                            float* run_mean, float* run_var, float* ws, hipStream_t st) {
+    if (!part || !mean || !rstd || !s || !b || !ws || P <= 0 || M <= 0 || C <= 0 || (!cnt && rows_per_part <= 0)) {
+        set_error("bn_stats_from_parts: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (!cnt && (long long)P * rows_per_part < M) {
+        set_error("bn_stats_from_parts: %d partials of %d rows do not cover %d rows", P, rows_per_part, M);
+        return ICAP_ERR_ARG;
+    }
+    if (P <= STAT_ONE_LAUNCH) {
+        hipLaunchKernelGGL(stat_finish_bn_kernel<false>, dim3((C + 63) / 64), dim3(256), 0, st, part, cnt, P, rows_per_part, gamma, beta, eps,
+                           momentum, M, C, mean, rstd, s, b, run_mean, run_var);
+        return launch_status("bn_stats_from_parts");
+    }
+    int nc, ppc;
+    stat_geometry(P, &nc, &ppc);
+    hipLaunchKernelGGL(stat_chunk_kernel, dim3((C + 63) / 64, nc), dim3(256), 0, st, part, cnt, P, ppc, rows_per_part, M, C, ws);
+    hipLaunchKernelGGL(stat_finish_bn_kernel<true>, dim3((C + 63) / 64), dim3(256), 0, st, ws, nullptr, nc, 0, gamma, beta, eps, momentum, M, C,
+                       mean, rstd, s, b, run_mean, run_var);
+    return launch_status("bn_stats_from_parts");
+}
+
 int bn_finalize_f32(const float* mean, const float* sqdev, const float* gamma, const float* beta, float eps, float momentum,
                     int M, int C, float* rstd, float* s, float* b, float* run_mean, float* run_var, hipStream_t st) {
     if (!mean || !sqdev || !rstd || !s || !b || M <= 0 || C <= 0) { set_error("bn_finalize: bad arguments"); return ICAP_ERR_ARG; }

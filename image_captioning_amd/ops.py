@@ -396,6 +396,106 @@ def linear(x, w, bias=None, scale=None, act=ACT_NONE, residual=None, out=None):
     return _linear_fp32(x, w, bias, scale, act, residual, out)
 
 
+class StatParts:
+    """Column statistics a producing kernel left for the train-mode BatchNorm that follows (train_ops.batchnorm_train):
+    part [P, 2, C] (sum, squared deviations per block of rows), cnt [P] values per block or None when block p holds
+    min(rows_per_part, M - p * rows_per_part) rows."""
+    __slots__ = ("part", "cnt", "P", "rows_per_part")
+
+    def __init__(self, part, cnt, P, rows_per_part):
+        self.part, self.cnt, self.P, self.rows_per_part = part, cnt, P, rows_per_part
+
+
+def _conv_stats(x4, w4, stride, pad, Ho, Wo):
+    """Plain convolution on the fp32 implicit-GEMM kernel + the column statistics of its result (icap_conv2d_stats_f32)."""
+    lib = N.load()
+    B, H, W, Cin = x4.shape
+    Cout, KH, KW, _ = w4.shape
+    pt, pb, pl, pr = pad
+    M = B * Ho * Wo
+    y = torch.empty((B, Ho, Wo, Cout), device=x4.device, dtype=torch.float32)
+    key = (B, H, W, Cin, Cout, KH, KW, stride, Ho, Wo)
+    if AUTOTUNE and key not in _tuned_shapes:
+        # first sight of the shape with tuning on: the tuning entry point measures the tile configurations (and computes y);
+        # the statistics launch below then runs the winner
+        _tuned_shapes.add(key)
+        N.check(lib.icap_conv2d_tune_f32(_ck(x4, "x"), _ck(w4, "w"), None, None, None, None, _ck(y, "y"), B, H, W, Cin, Cout, KH, KW,
+                                         stride, pt, pl, Ho, Wo, ACT_NONE, _stream()), "conv2d_tune")
+    cap = lib.icap_conv2d_stats_max_parts(M)
+    part = torch.empty((cap, 2, Cout), device=x4.device, dtype=torch.float32)
+    info = (C.c_int * 2)()
+    span = _Span("linear" if KH == 1 and H == 1 else "conv2d", (M, KH * KW * Cin, Cout, False) if KH == 1 and H == 1 else
+                 (B, H, W, Cin, Cout, KH, stride, Ho, Wo, False, False))
+    N.check(lib.icap_conv2d_stats_f32(_ck(x4, "x"), _ck(w4, "w"), _ck(y, "y"), B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo,
+                                      part.data_ptr(), part.numel(), C.cast(info, C.c_void_p), _stream()), "conv2d_stats")
+    span.done()
+    return y, StatParts(part, None, int(info[0]), int(info[1]))
+
+
+def conv2d_stats(x, w, *, stride=1, pad=(0, 0, 0, 0)):
+    """x [B,H,W,Cin], w [Cout,KH,KW,Cin] -> (y, StatParts): a convolution in front of a train-mode BatchNorm."""
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    Ho = conv_out_size(H, KH, stride, pad[0], pad[1])
+    Wo = conv_out_size(W, KW, stride, pad[2], pad[3])
+    if Cout % 4:
+        return conv2d(x, w, stride=stride, pad=pad), None
+    return _conv_stats(x, w, stride, pad, Ho, Wo)
+
+
+def linear_stats(x, w):
+    """y = x @ w^T plus the column statistics of y for the train-mode BatchNorm that follows -> (y, StatParts or None).
+    Same kernel choice as linear(); None when the chosen kernel has no statistics epilogue (the caller then takes the
+    statistics from y)."""
+    M, K = x.shape
+    Nn = w.shape[0]
+    if Nn % 4 or TRAIN_DTYPE == "bf16":
+        return linear(x, w), None
+    if TRAIN_DTYPE == "f32x3" and K % 8 == 0 and M >= TRAIN_BF16_MIN_ROWS:
+        def w3():
+            return step_cached("split3", w, lambda: split3(w.contiguous()))
+
+        def run_fp32():
+            return _linear_fp32(x, w, None, None, ACT_NONE, None, torch.empty((M, Nn), device=x.device, dtype=torch.float32))
+
+        def run_split(c):
+            return linear_f32x3(x, w3(), cfg=c)
+
+        c = _x3_pick(M, K, Nn, run_fp32, run_split)
+        if c != _X3_FP32:
+            lib = N.load()
+            y = torch.empty((M, Nn), device=x.device, dtype=torch.float32)
+            part = torch.empty(((M + 63) // 64 + 2, 2, Nn), device=x.device, dtype=torch.float32)
+            info = (C.c_int * 2)()
+            span = _Span("linear_f32x3", (M, K, Nn, False, False))
+            N.check(lib.icap_linear_f32x3_stats_f32(_ck(x, "x"), w3().data_ptr(), _ck(y, "y"), M, K, Nn, c, part.data_ptr(), part.numel(),
+                                                    C.cast(info, C.c_void_p), _stream()), "linear_f32x3_stats")
+            span.done()
+            return y, StatParts(part, None, int(info[0]), int(info[1]))
+    y, st = _conv_stats(x.view(M, 1, 1, K), w.view(Nn, 1, 1, K), 1, (0, 0, 0, 0), 1, 1)
+    return y.view(M, Nn), st
+
+
+def dwconv2d_stats(x, w, *, ks, stride=1, pad=(0, 0, 0, 0)):
+    """Plain depthwise convolution + the per-workgroup statistics of its result -> (y [B,Ho,Wo,C], StatParts)."""
+    B, H, W, Cc = x.shape
+    pt, pb, pl, pr = pad
+    Ho = conv_out_size(H, ks, stride, pt, pb)
+    Wo = conv_out_size(W, ks, stride, pl, pr)
+    if tuple(w.shape) != (ks * ks, Cc):
+        raise IcapError("dwconv2d: weight must be [ks*ks, C]")
+    lib = N.load()
+    y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    P = B * lib.icap_dwconv_chunks(Ho, Wo, Cc, ks, stride)
+    part = torch.empty((P, 2, Cc), device=x.device, dtype=torch.float32)
+    cnt = torch.empty(P, device=x.device, dtype=torch.float32)
+    span = _Span("dwconv2d", (B, H, W, Cc, ks, stride, Ho, Wo))
+    N.check(lib.icap_dwconv2d_stats_f32(_ck(x, "x"), _ck(w, "w"), _ck(y, "y"), B, H, W, Cc, ks, stride, pt, pl, Ho, Wo,
+                                        part.data_ptr(), cnt.data_ptr(), _stream()), "dwconv2d_stats")
+    span.done()
+    return y, StatParts(part, cnt, P, 0)
+
+
 def _linear_fp32(x, w, bias, scale, act, residual, out):
     M, K = x.shape
     Nn = w.shape[0]

@@ -110,12 +110,23 @@ def col_sum(a, out=None, accumulate=False, scale=1.0):
     return col_reduce(COL_SUM, a, out1=out, accumulate=accumulate, scale=scale)[0]
 
 
-def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NONE, res=None, out=None):
+def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NONE, res=None, out=None, parts=None):
     """BatchNorm over the rows of x [M, C] with batch statistics (+ activation, + residual); updates the running
-    statistics in place.  Returns (y, saved) with saved = (mean, rstd, s, b) for the backward pass."""
+    statistics in place.  Returns (y, saved) with saved = (mean, rstd, s, b) for the backward pass.
+    parts (ops.StatParts): the column statistics the kernel that produced x left behind - the pass over x that would
+    otherwise take them is skipped."""
     _ckr(x, "x")
     M, C = x.shape
     dev = x.device
+    if parts is not None:
+        mean = torch.empty(C, device=dev); rstd = torch.empty(C, device=dev); s = torch.empty(C, device=dev); b = torch.empty(C, device=dev)
+        lib = N.load()
+        ws = _ws(lib.icap_bn_stats_from_parts_ws_floats(parts.P, C), dev)
+        N.check(lib.icap_bn_stats_from_parts_f32(parts.part.data_ptr(), _p(parts.cnt), parts.P, parts.rows_per_part, M, C, _p(gamma), _p(beta),
+                                                 float(eps), float(momentum), mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), b.data_ptr(),
+                                                 _p(run_mean), _p(run_var), ws.data_ptr(), _stream()), "bn_stats_from_parts")
+        y = scale_bias_act(x, s, b, act=act, res=res, out=out)
+        return y, (mean, rstd, s, b)
     # one pass over x: moments about its first row (a sample of every column, so the subtraction stays benign); the second
     # pass of that reduction also derives mean / rstd / the fused scale and bias and updates the running statistics
     mean = torch.empty(C, device=dev); rstd = torch.empty(C, device=dev); s = torch.empty(C, device=dev); b = torch.empty(C, device=dev)

@@ -484,6 +484,29 @@ int icap_bn_finalize_moments_f32(const float* shift, const float* s1, const floa
 int icap_bn_train_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, float momentum, int M, int C,
                             float* mean, float* rstd, float* s, float* b, float* run_mean, float* run_var, float* ws, void* stream);
 
+/* Train-mode BatchNorm statistics WITHOUT a pass over the tensor: the kernel that produces a BatchNorm's input leaves, per
+ * block of result rows, every column's sum and its squared deviations about the block's own mean (stat_part [P][2][C]), and
+ * icap_bn_stats_from_parts_f32 merges the blocks (Chan's pairwise update, fixed order) into what icap_bn_train_stats_f32
+ * returns - mean, rstd, s, b and the running-statistics update.  The producers (no scale / bias / residual / gate /
+ * activation: a convolution in front of a BatchNorm has none, transformer_word_level_bahdnau.py:12-25 under model.train()):
+ *   icap_conv2d_stats_f32        icap_conv2d_f32's kernel (any tile configuration); info[0] = P, info[1] = rows per block;
+ *                                stat_part must hold icap_conv2d_stats_max_parts(M) * 2 * Cout floats (part_floats says so)
+ *   icap_linear_f32x3_stats_f32  icap_linear_f32x3_f32's kernel (fp32 x, cfg as there); info as above
+ *   icap_dwconv2d_stats_f32      icap_dwconv2d_f32's kernel; P = B * icap_dwconv_chunks(...), stat_cnt [P] = values per block
+ * icap_bn_stats_from_parts_f32: cnt = stat_cnt, or null when block p holds min(rows_per_part, M - p * rows_per_part) rows;
+ * ws: icap_bn_stats_from_parts_ws_floats(P, C) floats. */
+long long icap_conv2d_stats_max_parts(long long M);
+int icap_conv2d_stats_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                          int pad_t, int pad_l, int Ho, int Wo, float* stat_part, long long part_floats, int* info, void* stream);
+int icap_linear_f32x3_stats_f32(const float* x, const unsigned short* w3, float* y, int M, int K, int N, int cfg, float* stat_part,
+                                long long part_floats, int* info, void* stream);
+int icap_dwconv2d_stats_f32(const float* x, const float* w, float* y, int B, int H, int W, int C, int KS, int stride, int pad_t,
+                            int pad_l, int Ho, int Wo, float* stat_part, float* stat_cnt, void* stream);
+long long icap_bn_stats_from_parts_ws_floats(int P, int C);
+int icap_bn_stats_from_parts_f32(const float* part, const float* cnt, int P, int rows_per_part, int M, int C, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* mean, float* rstd, float* s, float* b,
+                                 float* run_mean, float* run_var, float* ws, void* stream);
+
 /* y = act(x * s[c] + b[c]) (+ res): normalisation + activation (+ identity skip) over [M][C]. */
 int icap_scale_bias_act_f32(const float* x, int ldx, const float* s, const float* b, const float* res, int ldr, int act,
                             int M, int C, float* y, int ldy, void* stream);

@@ -82,6 +82,8 @@ SIGNATURES = {
     "icap_argmax_rows_f32": (_i, [_p, _i, _p, _i, _i, _i, _p, _p]),
     "icap_linear_bf16_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "icap_to_bf16_f32": (_i, [_p, _p, _ll, _p]),
+    "icap_linear_x3dl_f32": (_i, [_p] * 7 + [_i] * 5 + [_p]),
+    "icap_linear_x3dl_argmax_f32": (_i, [_p] * 7 + [_i] * 3 + [_p]),
     "icap_split3_f32": (_i, [_p, _p, _ll, _p]),
     "icap_linear_f32x3_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "icap_linear_f32x3_argmax_f32": (_i, [_p, _i] + [_p] * 6 + [_i, _i, _i, _p]),

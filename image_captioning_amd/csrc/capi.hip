@@ -44,6 +44,10 @@ int linear_f32x3_f32(const float*, int, const unsigned short*, const float*, con
                      int, int, int, int, hipStream_t);
 int linear_f32x3_argmax_f32(const float*, int, const unsigned short*, const float*, const float*, float*, float*, int*, int, int, int,
                             hipStream_t);
+int linear_x3dl_f32(const unsigned short*, const unsigned short*, const float*, const float*, const float*, float*, unsigned short*, int, int,
+                    int, int, int, hipStream_t);
+int linear_x3dl_argmax_f32(const unsigned short*, const unsigned short*, const float*, const float*, float*, float*, int*, int, int, int,
+                           hipStream_t);
 int conv2d_bf16_f32(const void*, const unsigned short*, const float*, const float*, const void*, void*, int, int, int, int, int, int,
                     int, int, int, int, int, int, int, int, int, hipStream_t);
 int maxpool2d_bf16(const unsigned short*, unsigned short*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -230,6 +234,16 @@ int icap_linear_f32x3_f32(const void* x, int x_split, const unsigned short* w3, 
 int icap_linear_f32x3_argmax_f32(const void* x, int x_split, const unsigned short* w3, const float* scale, const float* bias,
                                  float* y, float* part_val, int* part_idx, int M, int K, int N, void* stream) {
     return linear_f32x3_argmax_f32((const float*)x, x_split, w3, scale, bias, y, part_val, part_idx, M, K, N, (hipStream_t)stream);
+}
+
+int icap_linear_x3dl_f32(const unsigned short* x3, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
+                         float* y, unsigned short* y3, int M, int K, int N, int act, int cfg, void* stream) {
+    return linear_x3dl_f32(x3, w3, scale, bias, residual, y, y3, M, K, N, act, cfg, (hipStream_t)stream);
+}
+
+int icap_linear_x3dl_argmax_f32(const unsigned short* x3, const unsigned short* w3, const float* scale, const float* bias, float* y,
+                                float* part_val, int* part_idx, int M, int K, int N, void* stream) {
+    return linear_x3dl_argmax_f32(x3, w3, scale, bias, y, part_val, part_idx, M, K, N, (hipStream_t)stream);
 }
 
 int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* stream) {

@@ -742,6 +742,46 @@ def linear_f32x3_argmax(x, w3, bias=None, scale=None, want_logits=False):
     return pv, pi, logits
 
 
+def linear_x3dl(x3, w3, bias=None, scale=None, act=ACT_NONE, residual=None, want_f32=True, want_split=False, cfg=-1):
+    """fp32-accurate y = act((x @ w^T) * scale + bias (+ residual)) from PRE-SPLIT operands streamed straight into LDS
+    (icap_linear_x3dl_f32): x3 = split3(x) [3, M, K], w3 = split3(w) [3, N, K], K % 32 == 0.  Returns (y fp32 or None,
+    y3 = split3(y) planes or None) - y3 feeds the next such GEMM without a separate split pass."""
+    if x3.dtype != torch.bfloat16 or x3.dim() != 3 or x3.shape[0] != 3 or w3.dtype != torch.bfloat16 or w3.shape[0] != 3:
+        raise IcapError("linear_x3dl: x3 and w3 must be split3() planes")
+    M, K = x3.shape[1], x3.shape[2]
+    Nn = w3.shape[1]
+    if w3.numel() // (3 * Nn) != K:
+        raise IcapError(f"linear_x3dl: x has K={K}, w3 is split3 of a [{Nn}, {w3.numel() // (3 * Nn)}] weight")
+    y = torch.empty((M, Nn), device=x3.device, dtype=torch.float32) if want_f32 else None
+    y3 = torch.empty((3, M, Nn), device=x3.device, dtype=torch.bfloat16) if want_split else None
+    if residual is not None and residual.numel() != M * Nn:
+        raise IcapError("linear_x3dl: residual has the wrong size")
+    span = _Span("linear_x3dl", (M, K, Nn, residual is not None, want_f32, want_split))
+    N.check(N.load().icap_linear_x3dl_f32(_ck(x3, "x3", torch.bfloat16), _ck(w3, "w3", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
+                                          _ck(residual, "residual"), _ck(y, "y"), _ck(y3, "y3", torch.bfloat16), M, K, Nn, act, cfg,
+                                          _stream()), "linear_x3dl")
+    span.done()
+    return y, y3
+
+
+def linear_x3dl_argmax(x3, w3, bias=None, scale=None, want_logits=False):
+    """Vocabulary projection from pre-split operands with fused arg-max partials per 128-column tile
+    (icap_linear_x3dl_argmax_f32) -> (part_val [M, P], part_idx [M, P], logits or None)."""
+    M, K = x3.shape[1], x3.shape[2]
+    Nn = w3.shape[1]
+    lib = N.load()
+    P = lib.icap_linear_bf16_argmax_parts(Nn)
+    pv = torch.empty((M, P), device=x3.device, dtype=torch.float32)
+    pi = torch.empty((M, P), device=x3.device, dtype=torch.int32)
+    logits = torch.empty((M, Nn), device=x3.device, dtype=torch.float32) if want_logits else None
+    span = _Span("linear_x3dl", (M, K, Nn, False, want_logits, False))
+    N.check(lib.icap_linear_x3dl_argmax_f32(_ck(x3, "x3", torch.bfloat16), _ck(w3, "w3", torch.bfloat16), _ck(scale, "scale"),
+                                            _ck(bias, "bias"), _ck(logits, "logits"), _ck(pv, "pv"), _ck(pi, "pi", torch.int32), M, K, Nn,
+                                            _stream()), "linear_x3dl_argmax")
+    span.done()
+    return pv, pi, logits
+
+
 def linear_bf16(x, w_bf16, bias=None, scale=None, act=ACT_NONE, residual=None, gate=None, hw=1, out=None, cfg=-1):
     """y[M,N] = act((x[M,K] (* gate[m // hw]) @ w[N,K]^T) * scale + bias (+ residual)) with bf16 products, fp32
     accumulation; w_bf16 from to_bf16(); x fp32 or bf16 (the bf16 result of a fused kernel), everything else fp32."""

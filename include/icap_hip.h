@@ -207,6 +207,17 @@ int icap_linear_f32x3_f32(const void* x, int x_split, const unsigned short* w3, 
 int icap_linear_f32x3_argmax_f32(const void* x, int x_split, const unsigned short* w3, const float* scale, const float* bias,
                                  float* y, float* part_val, int* part_idx, int M, int K, int N, void* stream);
 
+/* The same fp32-accurate split-product Linear with BOTH operands pre-split (x3 [3][M][K], w3 [3][N][K] from icap_split3_f32)
+ * and streamed global -> LDS without passing through registers (global_load_lds, a three-stage ring, one wait and one
+ * barrier per K slice of 32): the GEMMs of the batched greedy decoder (transformer_word_level.py:76-78: fc1, fc2, output_fc
+ * at M = images), whose activations are tiny against the weights.  y fp32 [M][N] and / or y3 - the result already as its
+ * three bf16 planes [3][M][N], i.e. the next GEMM's x3.  K % 32 == 0, N % 4 == 0.  cfg: -1 = by shape, 0 = 128x128 tiles,
+ * 1 = 64x64.  The arg-max form emits partials per 128-column tile (icap_linear_bf16_argmax_parts(N) per row). */
+int icap_linear_x3dl_f32(const unsigned short* x3, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
+                         float* y, unsigned short* y3, int M, int K, int N, int act, int cfg, void* stream);
+int icap_linear_x3dl_argmax_f32(const unsigned short* x3, const unsigned short* w3, const float* scale, const float* bias, float* y,
+                                float* part_val, int* part_idx, int M, int K, int N, void* stream);
+
 /* bf16-product form of icap_conv2d_f32 for the dense KH x KW convolutions of the ResNet-18 / VGG-16 encoders
  * (seq2seqbasic.py:19-35: torchvision conv3x3 + BN + ReLU, residual add): x [B][H][W][Cin] NHWC with Cin % 32 == 0,
  * w_bf16 [Cout][KH][KW][Cin] from icap_to_bf16_f32 - or Cin == 4 (the channel-padded RGB image of the first layer) with

@@ -173,13 +173,18 @@ template <int K, int S, int SW, int TX>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B,
                                                                 int H, int W, int C, int pad_t, int pad_l, int Ho, int Wo,
                                                                 int strips_w, int nstrips, int strips_per_chunk,
-                                                                float* __restrict__ part) {
+                                                                float* __restrict__ part, int col_blocks, int npairs) {
     constexpr int KK = K * K, TY = 256 / TX, NIN = (SW - 1) * S + K;
     __shared__ float4 red[TY][TX];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int c = (blockIdx.x * TX + tx) * 4;
-    const int chunk = blockIdx.y;
-    const int r = blockIdx.z;              // filter row of this workgroup: K accumulators per thread instead of K*K
+    // The K workgroups (filter rows) of one (channel block, chunk) pair read the same dy and neighbouring x rows: they take
+    // consecutive slots of ONE XCD (workgroup ids go to the XCDs round-robin), so that XCD's L2 serves K - 1 of the K reads.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / K) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int r = slot % K;                // filter row of this workgroup: K accumulators per thread instead of K*K
+    const int chunk = pair / col_blocks;
+    const int c = ((pair - chunk * col_blocks) * TX + tx) * 4;
     const int lo = chunk * strips_per_chunk, hi = min(nstrips, lo + strips_per_chunk);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc[K];
@@ -290,12 +295,12 @@ long long dwconv_bwd_weight_ws_floats(int B, int Ho, int Wo, int C, int K) {
 
 template <int K, int S, int SW>
 static void dww_launch(int tx, dim3 grid, hipStream_t st, const float* dy, const float* x, int B, int H, int W, int C, int pad_t,
-                       int pad_l, int Ho, int Wo, int strips_w, int nstrips, int per, float* ws) {
+                       int pad_l, int Ho, int Wo, int strips_w, int nstrips, int per, float* ws, int col_blocks, int npairs) {
     switch (tx) {
-        case 8: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 8>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws); break;
-        case 16: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 16>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws); break;
-        case 32: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 32>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws); break;
-        default: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 64>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws); break;
+        case 8: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 8>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws, col_blocks, npairs); break;
+        case 16: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 16>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws, col_blocks, npairs); break;
+        case 32: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 32>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws, col_blocks, npairs); break;
+        default: hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, SW, 64>), grid, dim3(256), 0, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, strips_w, nstrips, per, ws, col_blocks, npairs); break;
     }
 }
 
@@ -314,11 +319,15 @@ int dwconv_bwd_weight_f32(const float* dy, const float* x, int B, int H, int W, 
     const int nchunks = (nstrips + per - 1) / per;
     const int c4 = C / 4;
     const int tx = c4 <= 8 ? 8 : (c4 <= 16 ? 16 : (c4 <= 32 ? 32 : 64));
-    const dim3 grid((c4 + tx - 1) / tx, nchunks, K);
-    if (K == 3 && S == 1) dww_launch<3, 1, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws);
-    else if (K == 3) dww_launch<3, 2, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws);
-    else if (S == 1) dww_launch<5, 1, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws);
-    else dww_launch<5, 2, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws);
+    const int col_blocks = (c4 + tx - 1) / tx;
+    const long long npairs_ll = (long long)col_blocks * nchunks;
+    if (((npairs_ll + 7) / 8) * K * 8 > 0x7fffffffLL) { set_error("dwconv_bwd_weight: problem too large"); return ICAP_ERR_LIMIT; }
+    const int npairs = (int)npairs_ll;
+    const dim3 grid((unsigned)(((npairs + 7) / 8) * K * 8));
+    if (K == 3 && S == 1) dww_launch<3, 1, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws, col_blocks, npairs);
+    else if (K == 3) dww_launch<3, 2, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws, col_blocks, npairs);
+    else if (S == 1) dww_launch<5, 1, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws, col_blocks, npairs);
+    else dww_launch<5, 2, DWW_SW>(tx, grid, st, dy, x, B, H, W, C, pad_t, pad_l, Ho, Wo, (Wo + DWW_SW - 1) / DWW_SW, nstrips, per, ws, col_blocks, npairs);
     const int n = K * K * C;
     hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3((n + 7) / 8), dim3(256), 0, st, ws, nchunks, n, dw);
     return launch_status("dwconv_bwd_weight");

@@ -625,38 +625,59 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
     }
 }
 
+// The vector form: a thread owns ONE channel quad for the whole launch (the grid's stride is a multiple of the quads per
+// row), so the per-channel parameters are loaded once, and it keeps BWD_U row positions - 2 x BWD_U 16-byte loads - in flight.
+constexpr int BWD_U = 4;
+
 template <int ACT>      // >= 0: the activation fixed at compile time; < 0: the `act` argument decides per element
 __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ s, const float* __restrict__ b,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                              int act, int M, int C4, float* __restrict__ dx, int ldo) {
-    const unsigned total = (unsigned)M * (unsigned)C4;
     const float inv_m = 1.0f / (float)M;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const unsigned r = i / (unsigned)C4, c = (i - r * (unsigned)C4) << 2;
-        const float4 xq = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
-        const float4 dq = *reinterpret_cast<const float4*>(dy + (size_t)r * ldd + c);
-        const float xv[4] = {xq.x, xq.y, xq.z, xq.w}, dv[4] = {dq.x, dq.y, dq.z, dq.w};
-        // per-channel parameters as 16-byte loads as well (the channel vectors are 16-byte aligned: checked by the caller)
-        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 s4 = s ? *reinterpret_cast<const float4*>(s + c) : one;
-        const float4 b4 = b ? *reinterpret_cast<const float4*>(b + c) : zero;
-        const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-        float o[4];
+    const unsigned gtid = blockIdx.x * 256u + threadIdx.x;
+    const unsigned stride = gridDim.x * 256u;                 // a multiple of C4 (the launcher sees to it)
+    const unsigned row_step = stride / (unsigned)C4;
+    unsigned r = gtid / (unsigned)C4;
+    const unsigned c = (gtid - r * (unsigned)C4) << 2;
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 s4 = s ? *reinterpret_cast<const float4*>(s + c) : one;
+    const float4 b4 = b ? *reinterpret_cast<const float4*>(b + c) : zero;
+    const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+    float mv[4] = {0.f, 0.f, 0.f, 0.f}, kv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f}, ev[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mean) {
+        const float4 m4 = *reinterpret_cast<const float4*>(mean + c), r4 = *reinterpret_cast<const float4*>(rstd + c);
+        const float4 g4 = *reinterpret_cast<const float4*>(dgamma + c), e4 = *reinterpret_cast<const float4*>(dbeta + c);
+        mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+        kv[0] = r4.x; kv[1] = r4.y; kv[2] = r4.z; kv[3] = r4.w;
+        gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+        ev[0] = e4.x * inv_m; ev[1] = e4.y * inv_m; ev[2] = e4.z * inv_m; ev[3] = e4.w * inv_m;
+    }
+    for (; r < (unsigned)M; r += row_step * BWD_U) {
+        float4 xq[BWD_U], dq[BWD_U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = dv[k] * act_grad(fmaf(xv[k], sv[k], bv[k]), ACT >= 0 ? ACT : act);
-        if (mean) {
-            const float4 m4 = *reinterpret_cast<const float4*>(mean + c), r4 = *reinterpret_cast<const float4*>(rstd + c);
-            const float4 g4 = *reinterpret_cast<const float4*>(dgamma + c), e4 = *reinterpret_cast<const float4*>(dbeta + c);
-            const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
-            const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = o[k] - ev[k] * inv_m - (xv[k] - mv[k]) * rv[k] * gv[k] * inv_m;
+        for (int u = 0; u < BWD_U; ++u) {
+            const unsigned rr = min(r + u * row_step, (unsigned)M - 1u);     // clamped: every load is issued before the first use
+            xq[u] = *reinterpret_cast<const float4*>(x + (size_t)rr * ldx + c);
+            dq[u] = *reinterpret_cast<const float4*>(dy + (size_t)rr * ldd + c);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] *= sv[k];
-        *reinterpret_cast<float4*>(dx + (size_t)r * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+        for (int u = 0; u < BWD_U; ++u) {
+            const unsigned rr = r + u * row_step;
+            if (rr >= (unsigned)M) break;
+            const float xv[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w}, dv[4] = {dq[u].x, dq[u].y, dq[u].z, dq[u].w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = dv[k] * act_grad(fmaf(xv[k], sv[k], bv[k]), ACT >= 0 ? ACT : act);
+            if (mean) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = o[k] - ev[k] - (xv[k] - mv[k]) * kv[k] * gv[k] * inv_m;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] *= sv[k];
+            *reinterpret_cast<float4*>(dx + (size_t)rr * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 
@@ -668,8 +689,15 @@ int bn_act_bwd_f32(const float* dy, int ldd, const float* x, int ldx, const floa
         return ICAP_ERR_ARG;
     }
     if (vec4_ok(M, C, {ldd, ldx, ldo}, {dy, x, dx, s, b, mean, rstd, dgamma, dbeta})) {
-        long long vb = ((long long)M * (C / 4) + 255) / 256;
+        // grid x 256 threads must be a multiple of the quads per row (a thread keeps its channel quad): a multiple of
+        // C4 / gcd(C4, 256) workgroups, enough of them that a thread walks about BWD_U x 4 rows
+        const int C4 = C / 4;
+        int gcd = C4, t256 = 256;
+        while (t256) { const int t = gcd % t256; gcd = t256; t256 = t; }
+        const long long mult = C4 / gcd;
+        long long vb = ((long long)M * C4 + 256LL * BWD_U * 4 - 1) / (256LL * BWD_U * 4);
         if (vb > 16384) vb = 16384;
+        vb = (vb + mult - 1) / mult * mult;
         if (act == ACT_SWISH)
             hipLaunchKernelGGL(bn_act_bwd_vec_kernel<ACT_SWISH>, dim3((unsigned)vb), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma,
                                dbeta, act, M, C / 4, dx, ldo);

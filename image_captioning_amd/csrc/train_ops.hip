@@ -110,26 +110,28 @@ __global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __res
             bi = *reinterpret_cast<const float4*>(v4 + c);
         }
         if (MODE == COL_BN_BWD) {
-            // two rows per iteration, all four loads issued before the arithmetic; the second row is read from a clamped
-            // address and weighted 0 when it lies beyond the chunk
+            // four rows per iteration, all eight loads issued before the arithmetic; rows beyond the chunk are read from a
+            // clamped address and weighted 0
             const int actc = ACT >= 0 ? ACT : act;
-            for (int r = r_lo + ty; r < r_hi; r += 2 * TY) {
-                const int rb = min(r + TY, r_hi - 1);
-                const float wb = r + TY < r_hi ? 1.f : 0.f;
-                const float4 av = *reinterpret_cast<const float4*>(a + (size_t)r * lda + c);
-                const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
-                const float4 aw = *reinterpret_cast<const float4*>(a + (size_t)rb * lda + c);
-                const float4 xw = *reinterpret_cast<const float4*>(x + (size_t)rb * ldx + c);
-                const float g0 = av.x * act_grad(fmaf(xv.x, sc.x, bi.x), actc), g1 = av.y * act_grad(fmaf(xv.y, sc.y, bi.y), actc);
-                const float g2 = av.z * act_grad(fmaf(xv.z, sc.z, bi.z), actc), g3 = av.w * act_grad(fmaf(xv.w, sc.w, bi.w), actc);
-                s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
-                s2.x += g0 * ((xv.x - m.x) * rs.x); s2.y += g1 * ((xv.y - m.y) * rs.y);
-                s2.z += g2 * ((xv.z - m.z) * rs.z); s2.w += g3 * ((xv.w - m.w) * rs.w);
-                const float h0 = wb * aw.x * act_grad(fmaf(xw.x, sc.x, bi.x), actc), h1 = wb * aw.y * act_grad(fmaf(xw.y, sc.y, bi.y), actc);
-                const float h2 = wb * aw.z * act_grad(fmaf(xw.z, sc.z, bi.z), actc), h3 = wb * aw.w * act_grad(fmaf(xw.w, sc.w, bi.w), actc);
-                s1.x += h0; s1.y += h1; s1.z += h2; s1.w += h3;
-                s2.x += h0 * ((xw.x - m.x) * rs.x); s2.y += h1 * ((xw.y - m.y) * rs.y);
-                s2.z += h2 * ((xw.z - m.z) * rs.z); s2.w += h3 * ((xw.w - m.w) * rs.w);
+            constexpr int RU = 4;
+            for (int r = r_lo + ty; r < r_hi; r += RU * TY) {
+                float4 av[RU], xv[RU];
+                float wt[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int rr = min(r + u * TY, r_hi - 1);
+                    wt[u] = r + u * TY < r_hi ? 1.f : 0.f;
+                    av[u] = *reinterpret_cast<const float4*>(a + (size_t)rr * lda + c);
+                    xv[u] = *reinterpret_cast<const float4*>(x + (size_t)rr * ldx + c);
+                }
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const float g0 = wt[u] * av[u].x * act_grad(fmaf(xv[u].x, sc.x, bi.x), actc), g1 = wt[u] * av[u].y * act_grad(fmaf(xv[u].y, sc.y, bi.y), actc);
+                    const float g2 = wt[u] * av[u].z * act_grad(fmaf(xv[u].z, sc.z, bi.z), actc), g3 = wt[u] * av[u].w * act_grad(fmaf(xv[u].w, sc.w, bi.w), actc);
+                    s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
+                    s2.x += g0 * ((xv[u].x - m.x) * rs.x); s2.y += g1 * ((xv[u].y - m.y) * rs.y);
+                    s2.z += g2 * ((xv[u].z - m.z) * rs.z); s2.w += g3 * ((xv[u].w - m.w) * rs.w);
+                }
             }
         } else
         for (int r = r_lo + ty; r < r_hi; r += TY) {
@@ -210,9 +212,22 @@ __global__ __launch_bounds__(256) void col_finish_kernel(const float* __restrict
 }
 
 // rows per chunk: a few hundred workgroups in flight for tall matrices, at least 64 rows each
+// lanes along the channel axis (quads of channels) for the vector kernels: the width among 8 / 16 / 32 / 64 that leaves the
+// fewest idle lanes in the last column block (the wider one on ties), e.g. 24 quads -> 8 (three full blocks, not 24 of 32)
+static int col_vec_tx(int c4) {
+    int best = 64, best_waste = 1 << 30;
+    for (int tx = 64; tx >= 8; tx >>= 1) {
+        const int waste = (c4 + tx - 1) / tx * tx - c4;
+        if (waste < best_waste) { best_waste = waste; best = tx; }
+    }
+    return best;
+}
+
+// about 2048 workgroups in all (eight per CU: the reductions are bound by the bytes they keep in flight)
 static int col_rows_per_chunk(int M, int C) {
-    const int col_blocks = (C + 255) / 256 > 0 ? (C + 255) / 256 : 1;
-    long long want_chunks = 512 / col_blocks;
+    const int c4 = (C + 3) / 4, tx = col_vec_tx(c4);
+    const int col_blocks = (c4 + tx - 1) / tx;
+    long long want_chunks = 2048 / col_blocks;
     if (want_chunks < 1) want_chunks = 1;
     long long rows = (M + want_chunks - 1) / want_chunks;
     if (rows < 64) rows = 64;
@@ -263,7 +278,7 @@ static int col_partial_dispatch(int mode, const float* a, int lda, const float* 
     int nchunks;
     if (vec) {
         const int c4 = C / 4;
-        const int tx = c4 <= 8 ? 8 : (c4 <= 16 ? 16 : (c4 <= 32 ? 32 : 64));
+        const int tx = col_vec_tx(c4);
         const int rpc = col_rows_per_chunk(M, C);
         nchunks = (M + rpc - 1) / rpc;
         const dim3 grid((c4 + tx - 1) / tx, nchunks);

@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256) void se_train_bwd_image_kernel(const float* __
                                                                  int S) {
     __shared__ float dl[SET_MAX_C];
     __shared__ float dr[SET_MAX_S];
+    __shared__ float part2[4][SET_MAX_S];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int c = tid; c < C; c += 256) {
         const float g = sigmoid_fast(e[(size_t)b * C + c]);
@@ -454,17 +455,37 @@ __global__ __launch_bounds__(256) void se_train_bwd_image_kernel(const float* __
         de[(size_t)b * C + c] = d;
     }
     __syncthreads();
-    for (int j = wave; j < S; j += 4) {
-        float a = 0.f;
-#pragma unroll 8
-        for (int c = lane; c < C; c += 64) a = fmaf(we[(size_t)c * S + j], dl[c], a);
-        a = wave_sum_f(a);
-        if (lane == 0) {
-            const float x = r_pre[(size_t)b * S + j], sg = sigmoid_fast(x);
-            const float d = a * sg * (1.f + x * (1.f - sg));
-            dr[j] = d;
-            dr_pre[(size_t)b * S + j] = d;
+    // we^T de: a lane walks channels lane, lane + 64, ... of its wave's quarter and reads their rows of `we` contiguously
+    // (column-wise, one squeeze unit at a time, every lane touched a different cache line per load); the S partial sums of
+    // a wave meet in LDS and wave 0 adds the four quarters in order
+    {
+        constexpr int JB = 16;           // squeeze units per sweep over the channels
+        const int cq = (C + 3) / 4, c_lo = wave * cq, c_hi = min(C, c_lo + cq);
+        for (int j0 = 0; j0 < S; j0 += JB) {
+            float acc[JB];
+#pragma unroll
+            for (int j = 0; j < JB; ++j) acc[j] = 0.f;
+            for (int c = c_lo + lane; c < c_hi; c += 64) {
+                const float d = dl[c];
+                const float* w = we + (size_t)c * S + j0;
+#pragma unroll
+                for (int j = 0; j < JB; ++j) acc[j] = fmaf(w[min(j, S - 1 - j0)], j0 + j < S ? d : 0.f, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                const float t = wave_sum_f(acc[j]);
+                if (lane == 0 && j0 + j < S) part2[wave][j0 + j] = t;
+            }
         }
+    }
+    __syncthreads();
+    if (tid < S) {
+        const int j = tid;
+        const float a = ((part2[0][j] + part2[1][j]) + part2[2][j]) + part2[3][j];
+        const float x = r_pre[(size_t)b * S + j], sg = sigmoid_fast(x);
+        const float d = a * sg * (1.f + x * (1.f - sg));
+        dr[j] = d;
+        dr_pre[(size_t)b * S + j] = d;
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -482,7 +503,7 @@ __global__ __launch_bounds__(256) void se_train_bwd_weights_kernel(const float* 
                                                                    float* __restrict__ dwe, float* __restrict__ dbe,
                                                                    float* __restrict__ dwr, float* __restrict__ dbr, int B, int C,
                                                                    int S) {
-    constexpr int SG = 16, BT = 64;
+    constexpr int SG = 16, BT = 256;
     __shared__ float rl[BT][SG], dl[BT][SG];
     __shared__ float red[3][64][2 * SG + 1];
     const int tid = threadIdx.x, cl = tid & 63, slice = tid >> 6;
@@ -502,14 +523,29 @@ __global__ __launch_bounds__(256) void se_train_bwd_weights_kernel(const float* 
         }
         __syncthreads();
         const int nb = min(BT, B - b0);
-        for (int bb = slice; bb < nb; bb += 4) {
-            const float d = ok ? de[(size_t)(b0 + bb) * C + c] : 0.f;
-            const float pv = ok ? pooled[(size_t)(b0 + bb) * C + c] : 0.f;
-            sbe += d;
+        // eight images of this slice per round, their loads issued before the first is used (one image at a time the loop is a
+        // chain of 64 memory round trips); images beyond the batch read a clamped address and count as zero
+        constexpr int IU = 8;
+        const int cc = ok ? c : 0;
+        for (int bb = slice; bb < nb; bb += 4 * IU) {
+            float dv[IU], pvv[IU];
 #pragma unroll
-            for (int j = 0; j < SG; ++j) {
-                awe[j] = fmaf(d, rl[bb][j], awe[j]);
-                awr[j] = fmaf(dl[bb][j], pv, awr[j]);
+            for (int u = 0; u < IU; ++u) {
+                const int bi = min(bb + 4 * u, nb - 1);
+                dv[u] = de[(size_t)(b0 + bi) * C + cc];
+                pvv[u] = pooled[(size_t)(b0 + bi) * C + cc];
+            }
+#pragma unroll
+            for (int u = 0; u < IU; ++u) {
+                const int bi = bb + 4 * u;
+                if (bi >= nb) break;
+                const float d = ok ? dv[u] : 0.f, pv = ok ? pvv[u] : 0.f;
+                sbe += d;
+#pragma unroll
+                for (int j = 0; j < SG; ++j) {
+                    awe[j] = fmaf(d, rl[bi][j], awe[j]);
+                    awr[j] = fmaf(dl[bi][j], pv, awr[j]);
+                }
             }
         }
     }
@@ -535,7 +571,13 @@ __global__ __launch_bounds__(256) void se_train_bwd_weights_kernel(const float* 
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid < S) {
         float a = 0.f;
-        for (int b = 0; b < B; ++b) a += dr_pre[(size_t)b * S + tid];
+        for (int b = 0; b < B; b += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = dr_pre[(size_t)min(b + u, B - 1) * S + tid];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += b + u < B ? v[u] : 0.f;
+        }
         dbr[tid] = a;
     }
 }

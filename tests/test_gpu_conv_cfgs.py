@@ -29,6 +29,8 @@ SHAPES = [
     (3, 17, 15, 16, 40, 3, 2, (0, 1, 0, 1), 3, False, False),       # TF-same asymmetric 3x3 stride 2, K=144: 9 steps
     (5, 20, 20, 256, 96, 1, 1, (0, 0, 0, 0), 4, False, True),       # K=256: 16 steps; M=2000; SE gate; tanh
     (1024, 1, 1, 512, 6756, 1, 1, (0, 0, 0, 0), 0, False, False),   # the benchmark's vocabulary projection (weights outweigh rows)
+    (3, 21, 19, 32, 16, 1, 1, (0, 0, 0, 0), 0, False, True),        # a thin project convolution: K=32 (2 steps / 1 step of 32), Cout=16, SE gate
+    (2, 15, 15, 96, 24, 1, 1, (0, 0, 0, 0), 0, True, True),         # K=96: 6 steps / 3 steps of 32; residual + gate
     (7, 1, 1, 2048, 512, 1, 1, (0, 0, 0, 0), 1, True, False),       # few-row decoder GEMM: tiles mostly padding
 ]
 

@@ -432,20 +432,21 @@ int bn_train_stats_f32(const float* x, int ldx, const float* gamma, const float*
 // merged in index order), so the result does not depend on scheduling and no squares of un-centred values are ever formed.
 constexpr int STAT_U = 8;   // partials a thread keeps in flight
 
-// A workgroup = 64 columns x 4 row slots.  Slot k walks entries e0 + k, e0 + k + 4, ... of [e0, e1) with STAT_U loads in
-// flight, then the four slots are merged in order; slot 0 returns the column's statistics.  TRIPLE: entries are
+// A workgroup = TX columns x 256 / TX row slots.  Slot k walks entries e0 + k, e0 + k + slots, ... of [e0, e1) with STAT_U
+// loads in flight, then the slots are merged in order; slot 0 returns the column's statistics.  TRIPLE: entries are
 // (n, sum, q) triples [k][3][C] (the chunk results); otherwise raw partials [p][2][C] with their row counts.
-template <bool TRIPLE>
+template <bool TRIPLE, int TX>
 __device__ __forceinline__ ColStat stat_walk(const float* __restrict__ src, const float* __restrict__ cnt, int e0, int e1,
-                                             int rows_per_part, int M, int C, int c, float (*red)[3][64]) {
-    const int cx = threadIdx.x & 63, slot = threadIdx.x >> 6;
+                                             int rows_per_part, int M, int C, int c, float (*red)[3][TX]) {
+    constexpr int TY = 256 / TX;
+    const int cx = threadIdx.x % TX, slot = threadIdx.x / TX;
     ColStat a = {0.f, 0.f, 0.f};
     if (c < C) {
-        for (int eb = e0 + slot; eb < e1; eb += 4 * STAT_U) {
+        for (int eb = e0 + slot; eb < e1; eb += TY * STAT_U) {
             float sv[STAT_U], qv[STAT_U], nv[STAT_U];
 #pragma unroll
             for (int u = 0; u < STAT_U; ++u) {
-                const int ee = eb + 4 * u;
+                const int ee = eb + TY * u;
                 const int ec = min(ee, e1 - 1);
                 float n_here;
                 if constexpr (TRIPLE) {
@@ -467,7 +468,7 @@ __device__ __forceinline__ ColStat stat_walk(const float* __restrict__ src, cons
     __syncthreads();
     if (slot == 0) {
 #pragma unroll
-        for (int k = 1; k < 4; ++k) stat_merge(a, red[k][0][cx], red[k][1][cx], red[k][2][cx]);
+        for (int k = 1; k < TY; ++k) stat_merge(a, red[k][0][cx], red[k][1][cx], red[k][2][cx]);
     }
     return a;
 }
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void stat_chunk_kernel(const float* __restrict
     __shared__ float red[4][3][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int p0 = blockIdx.y * ppc, p1 = min(P, p0 + ppc);
-    const ColStat a = stat_walk<false>(part, cnt, p0, p1, rows_per_part, M, C, c, red);
+    const ColStat a = stat_walk<false, 64>(part, cnt, p0, p1, rows_per_part, M, C, c, red);
     if ((threadIdx.x >> 6) == 0 && c < C) {
         float* o = chunk_out + (size_t)blockIdx.y * 3 * C;
         o[c] = a.n; o[C + c] = a.s; o[2 * C + c] = a.q;
@@ -493,10 +494,11 @@ __global__ __launch_bounds__(256) void stat_finish_bn_kernel(const float* __rest
                                                              const float* __restrict__ beta, float eps, float momentum, int M, int C,
                                                              float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ s,
                                                              float* __restrict__ b, float* __restrict__ run_mean, float* __restrict__ run_var) {
-    __shared__ float red[4][3][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const ColStat a = stat_walk<TRIPLE>(src, cnt, 0, nent, rows_per_part, M, C, c, red);
-    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    // 16 columns x 16 slots: a few hundred entries per column are two to four rounds of loads
+    __shared__ float red[16][3][16];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const ColStat a = stat_walk<TRIPLE, 16>(src, cnt, 0, nent, rows_per_part, M, C, c, red);
+    if ((threadIdx.x >> 4) != 0 || c >= C) return;
     const float mu = a.n > 0.f ? a.s / a.n : 0.f;
     const float sq = fmaxf(a.q, 0.f);
     const float var = sq / (float)M;
@@ -539,14 +541,14 @@ int bn_stats_from_parts_f32(const float* part, const float* cnt, int P, int rows
         return ICAP_ERR_ARG;
     }
     if (P <= STAT_ONE_LAUNCH) {
-        hipLaunchKernelGGL(stat_finish_bn_kernel<false>, dim3((C + 63) / 64), dim3(256), 0, st, part, cnt, P, rows_per_part, gamma, beta, eps,
+        hipLaunchKernelGGL(stat_finish_bn_kernel<false>, dim3((C + 15) / 16), dim3(256), 0, st, part, cnt, P, rows_per_part, gamma, beta, eps,
                            momentum, M, C, mean, rstd, s, b, run_mean, run_var);
         return launch_status("bn_stats_from_parts");
     }
     int nc, ppc;
     stat_geometry(P, &nc, &ppc);
     hipLaunchKernelGGL(stat_chunk_kernel, dim3((C + 63) / 64, nc), dim3(256), 0, st, part, cnt, P, ppc, rows_per_part, M, C, ws);
-    hipLaunchKernelGGL(stat_finish_bn_kernel<true>, dim3((C + 63) / 64), dim3(256), 0, st, ws, nullptr, nc, 0, gamma, beta, eps, momentum, M, C,
+    hipLaunchKernelGGL(stat_finish_bn_kernel<true>, dim3((C + 15) / 16), dim3(256), 0, st, ws, nullptr, nc, 0, gamma, beta, eps, momentum, M, C,
                        mean, rstd, s, b, run_mean, run_var);
     return launch_status("bn_stats_from_parts");
 }

@@ -146,6 +146,83 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __res
     }
 }
 
+// Stride-2 form (the four down-sampling blocks of EfficientNet-B0: 3x3 with TF-'same' padding 0 / 1, 5x5 with 1 / 2).  Input
+// pixel (hi, wi) receives tap (r, q) of output pixel ((hi + PAD - r) / 2, (wi + PAD - q) / 2) when both differences are even, so
+// the four pixels of a 2 x 2 input block (a, b) use the same NDY x NDY window of dy around (a, b) with disjoint tap sets.  A
+// thread owns one channel quad and TB = 4 adjacent blocks of one block row: it loads the NDY x (TB + NDY - 1) window once
+// (every load unconditional from a clamped address, zeroed by a select) and produces 16 input pixels - 1.3 (3x3) or 2.3 (5x5)
+// dy loads per pixel quad instead of up to 4 / 9 conditional ones, and no division or parity test per tap.
+template <int K, int PAD>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w, int B, int H,
+                                                                 int W, int C4, int Ho, int Wo, int nstrips_w, int nstrips,
+                                                                 float* __restrict__ dx) {
+    constexpr int TB = 4;
+    constexpr int DMIN = -((K - 1 - PAD) / 2);                   // smallest (i + PAD - r) / 2: i = 0 (or 1), r = K - 1 (or K - 2)
+    constexpr int DMAX = (1 + PAD) / 2;                           // largest: i = 1, r = (1 + PAD) % 2
+    constexpr int NDY = DMAX - DMIN + 1, NW = TB + NDY - 1;
+    const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * nstrips * C4;
+    if (gi >= total) return;
+    const int cq = (int)(gi % C4);
+    const long long t1 = gi / C4;
+    const int strip = (int)(t1 % nstrips), b = (int)(t1 / nstrips);
+    const int a = strip / nstrips_w, b0 = (strip - a * nstrips_w) * TB;
+    const int C = C4 * 4, c = cq * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 d[NDY][NW];
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+        const int ho = a + DMIN + u;
+        const bool rok = (unsigned)ho < (unsigned)Ho;
+        const float* row = dy + (((size_t)b * Ho + (rok ? ho : 0)) * Wo) * C + c;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) {
+            const int wo = b0 + DMIN + v;
+            const bool ok = rok && (unsigned)wo < (unsigned)Wo;
+            d[u][v] = *reinterpret_cast<const float4*>(row + (size_t)(ok ? wo : 0) * C);
+            if (!ok) d[u][v] = z4;
+        }
+    }
+    float4 acc[TB][2][2];
+#pragma unroll
+    for (int t = 0; t < TB; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = z4;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        constexpr int dummy = 0; (void)dummy;
+        const int i = (r + PAD) & 1;                 // the block row parity this filter row serves
+        const int u = (i + PAD - r) / 2 - DMIN;      // (i + PAD - r) is even
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int j = (q + PAD) & 1;
+            const int v0 = (j + PAD - q) / 2 - DMIN;
+            const float4 ww = *reinterpret_cast<const float4*>(w + (size_t)(r * K + q) * C + c);
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const float4 dv = d[u][v0 + t];
+                acc[t][i][j].x = fmaf(dv.x, ww.x, acc[t][i][j].x); acc[t][i][j].y = fmaf(dv.y, ww.y, acc[t][i][j].y);
+                acc[t][i][j].z = fmaf(dv.z, ww.z, acc[t][i][j].z); acc[t][i][j].w = fmaf(dv.w, ww.w, acc[t][i][j].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int hi = 2 * a + i;
+        if (hi >= H) continue;
+        float* orow = dx + (((size_t)b * H + hi) * W) * C + c;
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int wi = 2 * (b0 + t) + j;
+                if (wi < W) *reinterpret_cast<float4*>(orow + (size_t)wi * C) = acc[t][i][j];
+            }
+    }
+}
+
 int dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, int C, int K, int S, int pad_t, int pad_l, int Ho,
                         int Wo, float* dx, hipStream_t st) {
     if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || S <= 0 || Ho <= 0 || Wo <= 0) {
@@ -153,6 +230,16 @@ int dwconv_bwd_data_f32(const float* dy, const float* w, int B, int H, int W, in
         return ICAP_ERR_ARG;
     }
     if (C % 4 || !aligned16(dy) || !aligned16(w) || !aligned16(dx)) { set_error("dwconv_bwd_data: C %% 4 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
+    if (S == 2 && pad_t == pad_l && ((K == 3 && pad_t == 0) || (K == 5 && pad_t == 1)) && Ho == (H + 1) / 2 && Wo == (W + 1) / 2) {
+        // every input pixel lies in a 2 x 2 block whose window of dy is inside [0, Ho) x [0, Wo) or zero
+        const int nsw = ((W + 1) / 2 + 3) / 4, nstrips = ((H + 1) / 2) * nsw;
+        const long long threads = (long long)B * nstrips * (C / 4);
+        const long long nb = (threads + 255) / 256;
+        if (nb > 0x7fffffffLL) { set_error("dwconv_bwd_data: problem too large"); return ICAP_ERR_LIMIT; }
+        if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<3, 0>), dim3((unsigned)nb), dim3(256), 0, st, dy, w, B, H, W, C / 4, Ho, Wo, nsw, nstrips, dx);
+        else hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<5, 1>), dim3((unsigned)nb), dim3(256), 0, st, dy, w, B, H, W, C / 4, Ho, Wo, nsw, nstrips, dx);
+        return launch_status("dwconv_bwd_data");
+    }
     const long long total = (long long)B * H * W * (C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;

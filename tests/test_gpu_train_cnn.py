@@ -15,7 +15,9 @@ def rnd(*shape, seed=0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed + sum(shape)))
 
 
-@pytest.mark.parametrize("B,H,W,C,K,S", [(2, 14, 14, 48, 3, 1), (2, 15, 15, 24, 5, 2), (3, 8, 8, 16, 3, 2), (1, 7, 7, 64, 5, 1)])
+@pytest.mark.parametrize("B,H,W,C,K,S", [(2, 14, 14, 48, 3, 1), (2, 15, 15, 24, 5, 2), (3, 8, 8, 16, 3, 2), (1, 7, 7, 64, 5, 1),
+                                         (2, 14, 14, 24, 5, 2), (2, 28, 28, 40, 3, 2), (2, 10, 14, 8, 5, 2), (3, 6, 22, 12, 3, 2),
+                                         (1, 56, 56, 144, 5, 2)])
 def test_depthwise_gradients(B, H, W, C, K, S):
     from image_captioning_amd import train_ops as T
     from image_captioning_amd.backbones import same_pad

@@ -79,7 +79,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // PF: K slices in flight in registers (the number of K steps must be a multiple of it).  A
 // workgroup that is alone on its CU - few-tile problems such as the decoder GEMMs at 256 rows -
 // otherwise stalls every step for the part of the memory latency one step of MFMAs does not cover.
-template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC, int PF = 1, bool AMAX = false, bool FRAG = false>
+// STATS: the epilogue also leaves the column statistics of the result (its own instantiation: the moments it carries cost
+// registers - and with them a resident wave per SIMD on the thin-result tiles - that the other launches should not pay).
+template <int BM, int BN, int WM, int WN, int KSPLIT, int KU, bool ONE_BY_ONE, bool GATE, bool VEC, int PF = 1, bool AMAX = false, bool FRAG = false,
+          bool STATS = false>
 __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = 64 * WM * WN * KSPLIT;   // threads: one wave per (row block, column block, K split)
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
                             }
                 }
                 __syncthreads();
-                if (pass == 0 && p.stat_part) {
+                if (STATS && pass == 0) {
                     // the tile's first row (split-K planes added): a sample of every column to centre the moments on
                     st_shift = *reinterpret_cast<const float4*>(&ep[en4 * 4]);
                     if (tid < BN) my_shift = ep[tid];
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
                         const float4 o = *reinterpret_cast<const float4*>(&ep[(k2 * EP_R + row) * EP_LD + en4 * 4]);
                         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     }
-                    if (p.stat_part) stat_acc4(st_s1, st_s2, v, st_shift);
+                    if constexpr (STATS) stat_acc4(st_s1, st_s2, v, st_shift);
                     v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
                     v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
                     const size_t o = (size_t)m * p.ldy + n;
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_igemm_kernel(const
                             }
                     }
                 }
-                if (pass == NPASS - 1 && p.stat_part) {
+                if (STATS && pass == NPASS - 1) {
                     // column statistics of the result for the BatchNorm that follows: the row groups' shifted moments meet
                     // in LDS (the tile image is dead once every thread has read its rows) and one thread per column adds
                     // them in order
@@ -616,16 +619,26 @@ static int launch_cfg(ConvParams& p, hipStream_t st) {
     p.nblk = (int)blocks;
     const bool one = (p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0);
     const dim3 block(64 * WM * WN * KSPLIT);
-#define ICAP_LAUNCH(O_, G_)                                                                          \
+#define ICAP_LAUNCH(O_, G_, S_)                                                                      \
     do {                                                                                             \
         static int cached = 0;                                                                       \
-        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC, PF, AMAX, FRAG>;                               \
+        auto kern = conv_igemm_kernel<BM, BN, WM, WN, KSPLIT, KU, O_, G_, VEC, PF, AMAX, FRAG, S_>;                           \
         hipLaunchKernelGGL(kern, dim3((unsigned)persistent_grid(kern, p.nblk, cached, (int)block.x)), block, 0, st, p); \
     } while (0)
-    if (one && p.gate) ICAP_LAUNCH(true, true);
-    else if (one) ICAP_LAUNCH(true, false);
-    else if (p.gate) ICAP_LAUNCH(false, true);
-    else ICAP_LAUNCH(false, false);
+    if (p.stat_part) {
+        if constexpr (VEC && !AMAX) {
+            if (p.gate) { set_error("conv_igemm: the statistics epilogue takes no gate"); return ICAP_ERR_ARG; }
+            if (one) ICAP_LAUNCH(true, false, true);
+            else ICAP_LAUNCH(false, false, true);
+        } else {
+            set_error("conv_igemm: this configuration has no statistics epilogue");
+            return ICAP_ERR_ARG;
+        }
+    }
+    else if (one && p.gate) ICAP_LAUNCH(true, true, false);
+    else if (one) ICAP_LAUNCH(true, false, false);
+    else if (p.gate) ICAP_LAUNCH(false, true, false);
+    else ICAP_LAUNCH(false, false, false);
 #undef ICAP_LAUNCH
     return launch_status("conv_igemm");
 }

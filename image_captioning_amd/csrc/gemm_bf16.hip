@@ -85,7 +85,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // decoder's vocabulary projection: 53) would otherwise repeat the split arithmetic of x in every one of them.
 // Its three operand planes are single-buffered in LDS (60 KB for a 128 x 128 x 32 tile) so that TWO workgroups share a CU:
 // one workgroup's staging phase (global-load wait, the split arithmetic, LDS stores) runs under the other's MFMA phase.
-template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, int CONV = 0, int SPLIT = 1>
+// STATS: the epilogue also leaves the column statistics of the result for a train-mode BatchNorm (its own instantiation, so
+// that the registers its moments take are paid by those launches only).
+template <int BM, int BN, bool GATE, bool AMAX = false, bool A16 = false, int CONV = 0, int SPLIT = 1, bool STATS = false>
 __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(const GemmBf16Params p) {
     static_assert(!(CONV && (GATE || AMAX)) && !(CONV == 2 && A16), "the convolution form has no gate / arg-max; its 4-channel form reads fp32");
     static_assert(SPLIT == 1 || (SPLIT == 3 && CONV == 0 && !(A16 && GATE)), "split products: linear form; pre-split activations take no gate");
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                         }
             }
             __syncthreads();
-            if (pass == 0 && p.stat_part) {
+            if (STATS && pass == 0) {
                 st_shift = *reinterpret_cast<const float4*>(&ep[en4 * 4]);        // the tile's first row: a sample of every column
                 if (tid < BN) my_shift = ep[tid];
             }
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                 }
                 if (m >= p.M || n >= p.N) continue;
                 float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
-                if (p.stat_part) stat_acc4(st_s1, st_s2, v, st_shift);
+                if constexpr (STATS) stat_acc4(st_s1, st_s2, v, st_shift);
                 v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
                 v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
                 const size_t o = (size_t)m * p.N + n;
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                 if (p.y16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + o) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
                 else *reinterpret_cast<float4*>(p.y + o) = v;
             }
-            if (pass == NPASS - 1 && p.stat_part) {
+            if (STATS && pass == NPASS - 1) {
                 // column statistics of the result for the BatchNorm that follows: the row groups' shifted moments meet in
                 // LDS (the tile image is dead once every thread has read its rows) and one thread per column adds them in order
                 __syncthreads();
@@ -630,16 +632,16 @@ constexpr int gb16_split_smem() {
     return stage > ep ? stage : ep;
 }
 
-template <int BM, int BN, bool GATE, bool AMAX, bool A3 = false>
+template <int BM, int BN, bool GATE, bool AMAX, bool A3 = false, bool STATS = false>
 static int gb16_split_launch(GemmBf16Params& p, hipStream_t st) {
-    static hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, GATE, AMAX, A3, 0, 3>),
+    static hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, GATE, AMAX, A3, 0, 3, STATS>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, gb16_split_smem<BM, BN>());
     if (attr_rc != hipSuccess) { set_error("linear_f32x3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr_rc)); return ICAP_ERR_HIP_BASE + (int)attr_rc; }
     p.tiles_n = (p.N + BN - 1) / BN;
     gb16_set_order(p, A3 ? 6 : 4, 6);
     const dim3 grid((unsigned)((long long)((p.M + BM - 1) / BM) * p.tiles_n)), block(256);
     constexpr int lds_bytes = gb16_split_smem<BM, BN>();
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, GATE, AMAX, A3, 0, 3>), grid, block, lds_bytes, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, GATE, AMAX, A3, 0, 3, STATS>), grid, block, lds_bytes, st, p);
     return launch_status("linear_f32x3");
 }
 
@@ -710,9 +712,9 @@ int linear_f32x3_stats_f32(const float* x, const unsigned short* w3, float* y, i
     info[1] = bm;
     p.stat_part = stat_part;
     switch (cfg) {
-        case 0: return gb16_split_launch<128, 128, false, false>(p, st);
-        case 1: return gb16_split_launch<64, 128, false, false>(p, st);
-        default: return gb16_split_launch<64, 64, false, false>(p, st);
+        case 0: return gb16_split_launch<128, 128, false, false, false, true>(p, st);
+        case 1: return gb16_split_launch<64, 128, false, false, false, true>(p, st);
+        default: return gb16_split_launch<64, 64, false, false, false, true>(p, st);
     }
 }
 

@@ -81,6 +81,7 @@ SIGNATURES = {
     "icap_layernorm_f32": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _f, _f, _p]),
     "icap_argmax_rows_f32": (_i, [_p, _i, _p, _i, _i, _i, _p, _p]),
     "icap_linear_bf16_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "icap_header_hash": (C.c_uint, []),
     "icap_to_bf16_f32": (_i, [_p, _p, _ll, _p]),
     "icap_linear_x3dl_f32": (_i, [_p] * 7 + [_i] * 5 + [_p]),
     "icap_linear_x3dl_argmax_f32": (_i, [_p] * 7 + [_i] * 3 + [_p]),
@@ -166,6 +167,36 @@ SIGNATURES = {
 _lib = None
 
 
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "icap_hip.h")
+
+
+def header_hash():
+    """POSIX cksum CRC of include/icap_hip.h (what the Makefile bakes into the library), None when the header is not there."""
+    try:
+        data = open(HEADER_PATH, "rb").read()
+    except OSError:
+        return None
+    crc = 0
+    table = _cksum_table()
+    for b in data:
+        crc = ((crc << 8) & 0xFFFFFFFF) ^ table[((crc >> 24) ^ b) & 0xFF]
+    n = len(data)
+    while n:
+        crc = ((crc << 8) & 0xFFFFFFFF) ^ table[((crc >> 24) ^ (n & 0xFF)) & 0xFF]
+        n >>= 8
+    return (~crc) & 0xFFFFFFFF
+
+
+def _cksum_table():
+    t = []
+    for i in range(256):
+        c = i << 24
+        for _ in range(8):
+            c = ((c << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if c & 0x80000000 else (c << 1) & 0xFFFFFFFF
+        t.append(c)
+    return t
+
+
 def load():
     """Load the shared library once; raise IcapError when it is absent or stale."""
     global _lib
@@ -189,6 +220,10 @@ def load():
         fn.argtypes = args
     if lib.icap_abi_version() != ABI_VERSION:
         raise IcapError(f"ABI mismatch: library {lib.icap_abi_version()} vs binding {ABI_VERSION}")
+    built, here = lib.icap_header_hash(), header_hash()
+    if built and here is not None and built != here:
+        raise IcapError(f"{LIB_PATH} was built against another version of include/icap_hip.h (cksum {built}, the header here has "
+                        f"{here}): rebuild it with `make -C image_captioning_amd/csrc`")
     _lib = lib
     return lib
 

@@ -162,6 +162,11 @@ using namespace icap;
 extern "C" {
 
 int icap_abi_version(void) { return ICAP_ABI_VERSION; }
+
+#ifndef ICAP_HEADER_HASH
+#define ICAP_HEADER_HASH 0u
+#endif
+unsigned icap_header_hash(void) { return ICAP_HEADER_HASH; }
 const char* icap_last_error(void) { return g_err; }
 
 int icap_nchw_to_nhwc_pad_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream) {

@@ -36,6 +36,10 @@ extern "C" {
 #define ICAP_ACT_TANH 4
 
 int icap_abi_version(void);
+/* POSIX cksum (CRC) of the icap_hip.h the library was compiled against, 0 when the build did not record one: a binding that
+ * ships with the header compares the two and refuses a library built from another version of this file (a changed
+ * signature under an unchanged name would otherwise go unnoticed). */
+unsigned icap_header_hash(void);
 const char* icap_last_error(void);
 
 /* ------------------------------------------------------------------ encoder */

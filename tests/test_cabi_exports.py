@@ -43,3 +43,14 @@ def test_argument_checks_need_no_gpu():
     assert lib.icap_expand_dwconv_whole_image(28, 28, 40, 240, 5, 1) == 0
     assert lib.icap_stem_dwconv_chunks(112, 112, 32) == 64
     assert lib.icap_greedy_tfm_ws_floats(8, 512, 2048, 6756) > 8 * 512 * 4
+
+
+def test_library_was_built_against_this_header():
+    """The Makefile bakes the POSIX cksum of include/icap_hip.h into the library; a library built from another version of
+    the header (a changed signature under an unchanged name) is refused at load time."""
+    from image_captioning_amd import _native as N
+    import ctypes
+    lib = ctypes.CDLL(N.LIB_PATH)
+    lib.icap_header_hash.restype = ctypes.c_uint
+    assert N.header_hash() is not None
+    assert lib.icap_header_hash() == N.header_hash()

@@ -141,3 +141,39 @@ def test_trainer_rejects_unknown_dtype():
     from image_captioning_amd.training import Trainer
     with pytest.raises(ValueError):
         Trainer(torch.nn.Linear(2, 2), dtype="fp8")
+
+
+def test_decode_weight_switch():
+    """bf16 weight streaming of the small-batch decode drivers: explicit switch, or implied by the bf16 compute mode."""
+    try:
+        assert not ops.decode_weights_bf16()
+        ops.set_decode_weights("bf16")
+        assert ops.decode_weights_bf16()
+        ops.set_decode_weights("f32")
+        ops.set_compute_dtype("bf16")
+        assert not ops.decode_weights_bf16()            # an explicit choice wins over the compute mode
+        ops.set_decode_weights(None)
+        assert ops.decode_weights_bf16()                # no choice: follow the compute mode
+        with pytest.raises(ops.IcapError):
+            ops.set_decode_weights("fp8")
+    finally:
+        ops.set_decode_weights(None)
+        ops.set_compute_dtype("f32")
+
+
+def test_bf16_weight_copies_need_rows_of_eight_and_a_device():
+    wd = {"fc_w": torch.zeros(5, 12)}
+    with pytest.raises(ops.IcapError):
+        ops._w16(wd, "fc_w")                            # 12 is not a multiple of 8
+    wd = {"fc_w": torch.zeros(5, 16)}
+    with pytest.raises(ops.IcapError):
+        ops._w16(wd, "fc_w")                            # a CPU tensor: there is no CPU path
+
+
+def test_stat_parts_descriptor_and_cpu_rejection():
+    sp = ops.StatParts(torch.zeros(3, 2, 8), None, 3, 64)
+    assert (sp.P, sp.rows_per_part, sp.cnt) == (3, 64, None)
+    for fn, args in ((ops.linear_stats, (torch.zeros(70, 16), torch.zeros(8, 16))),
+                     (ops.linear_x3dl, (torch.zeros(3, 4, 32, dtype=torch.bfloat16), torch.zeros(3, 8, 32, dtype=torch.bfloat16)))):
+        with pytest.raises(ops.IcapError):
+            fn(*args)

@@ -61,9 +61,10 @@ def _conv1x1(tape, x, conv, need_dx=True):
     w = _w2d(conv)
     z, parts = ops.linear_stats(x, w)
 
-    def bwd(dz):
+    def bwd(dz, add=None):
+        """add: the gradient an identity skip brings to the same input, added in the input-gradient GEMM's epilogue"""
         tape.grad(conv.weight, T.gemm_tn(dz, x))
-        return T.gemm_nn(dz, w) if need_dx else None
+        return T.gemm_nn(dz, w, add=add) if need_dx else None
     return z, parts, bwd
 
 
@@ -122,9 +123,10 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
         dww = T.dwconv_bwd_weight(dz1, a0, B, H, W, mid, k, stride, lo, lo, Ho, Wo)
         tape.grad(blk._depthwise_conv.weight, dww.t().contiguous().view(mid, 1, k, k))
         d = T.dwconv_bwd_data(dz1, dw_w, B, H, W, mid, k, stride, lo, lo, Ho, Wo)
-        for f in reversed(bw):
-            d = f(d)
-        if skip:
+        if bw:
+            d = bw[1](d)                                     # BatchNorm + swish of the expand convolution
+            d = bw[0](d, dy if skip else None)               # its input gradient (+ the skip's gradient in the epilogue)
+        elif skip:
             T.axpby(dy, d)
         return d
     tape.add(bwd)

@@ -40,13 +40,22 @@ def transpose(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
-    """out[M, N] (+)= a[M, K] @ b[K, N]  (input gradient of a Linear: dX = dY @ W)."""
+def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False,
+            add: torch.Tensor | None = None) -> torch.Tensor:
+    """out[M, N] (+)= a[M, K] @ b[K, N]  (input gradient of a Linear: dX = dY @ W).  add [M, N]: a second gradient flowing
+    into the same tensor (an identity skip), added in the GEMM's epilogue instead of by a pass of its own."""
     _ckr(a, "a"); _ckr(b, "b")
     M, K = a.shape
     K2, Nn = b.shape
     if K != K2:
         raise N.IcapError(f"gemm_nn: inner sizes differ ({K} vs {K2})")
+    if add is not None:
+        if out is not None or accumulate or tuple(add.shape) != (M, Nn) or not add.is_contiguous():
+            raise N.IcapError("gemm_nn: `add` needs a fresh result and a contiguous [M, N] tensor")
+        if K % 4 == 0 and Nn % 4 == 0 and a.stride(0) == K and M >= 64:
+            bt = ops.step_cached("transposed", b, lambda: transpose(b))
+            return ops.linear(a, bt, residual=add)
+        return axpby(add, gemm_nn(a, b))
     if out is None:
         out = torch.empty(M, Nn, device=a.device, dtype=torch.float32)
         accumulate = False

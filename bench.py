@@ -698,7 +698,9 @@ def main():
             try:
                 return train_secondary(torch, dist, ops, dev, world, rank, max(1, min(args.steps, 10)), args.train_batch,
                                        "f32x3" if args.dtype == "f32x3" else "f32")
-            except Exception as e:      # noqa: BLE001 - reported in the line
+            except Exception as e:      # noqa: BLE001 - reported in the line (rank 0) and on stderr (every rank)
+                import traceback
+                note(rank, "train secondary failed: " + "".join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:])
                 return {"error": f"{type(e).__name__}: {e}"[:300]}
 
         res = with_deadline(args.train_deadline, emit_without, run)

@@ -182,6 +182,9 @@ class CnnTrain(torch.autograd.Function):
             da = T.chan_affine(None, None, dpool, 1.0 / HW, B, HW, 1280)
             return head_bwd(bn1_bwd(da))
         tape.add(head)
+        # the closures hold the tape (for tape.grad); the tape must not hold them back, or a step's activations would
+        # sit in a reference cycle until Python's cycle collector happens to run
+        ctx.steps, tape.steps = tape.steps, None
         ctx.tape = tape
         ctx.params = params
         return out
@@ -190,9 +193,11 @@ class CnnTrain(torch.autograd.Function):
     def backward(ctx, dout):
         tape = ctx.tape
         d = dout.float().contiguous()
-        for f in reversed(tape.steps):
+        for f in reversed(ctx.steps):
             d = f(d)
-        return (None, None, None) + tuple(tape.grads.get(id(p)) for p in ctx.params)
+        grads = tuple(tape.grads.get(id(p)) for p in ctx.params)
+        tape.grads = {}
+        return (None, None, None) + grads
 
 
 def cnn_train(model, images, masks=None):

@@ -127,6 +127,9 @@ WORK = {"linear_f32x3": linear_x3_work, "linear_bf16": lambda s: linear_bf16_wor
         "col_reduce": lambda s: (2.0 * s[1] * s[2], 4.0 * s[1] * s[2] * (2 if s[0] >= 2 else 1)),
         "scale_bias_act": lambda s: (2.0 * s[0] * s[1], 4.0 * s[0] * s[1] * (3 if s[2] else 2)),
         "bn_act_bwd": lambda s: (8.0 * s[0] * s[1], 4.0 * s[0] * s[1] * 3),
+        # both passes of the gated form: the sums read dy and x, the apply reads them again and writes dx
+        "bn_act_bwd_se": lambda s: (18.0 * s[0] * s[1], 4.0 * s[0] * s[1] * 5),
+        "act_pool": lambda s: (3.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * 2),
         "chan_affine": lambda s: (2.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * (2 if s[3] else 1)),
         "se_train_fwd": lambda s: (4.0 * s[0] * s[1] * s[2], 4.0 * (3 * s[0] * s[1] + 2 * s[1] * s[2])),
         "se_train_bwd": lambda s: (8.0 * s[0] * s[1] * s[2], 4.0 * (5 * s[0] * s[1] + 4 * s[1] * s[2])),

@@ -216,7 +216,6 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         dWs = torch.empty(Tn, B, A, device=dev)
         dApart = torch.empty(Tn, B, A, device=dev)
         dAb = torch.empty(Tn, B, device=dev)
-        dEmb = torch.empty(Tn * B, E, device=dev)
         du = torch.zeros(B, A, device=dev)
         dfeat = torch.zeros(B, ENC, device=dev)
         dh_next = torch.zeros(B, H, device=dev)
@@ -226,7 +225,6 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         for t in reversed(range(Tn)):
             dh = T.axpby(dHs[t], dh_next)                                          # dh_next += dHs[t]
             dg, dc_next = T.lstm_bwd(G[t], Cs[t], Cs[t + 1], dh, dc_next, dg_out=dG[t])
-            T.gemm_nn(dg, w_ih_d[:, :E], out=dEmb[t * B:(t + 1) * B])
             dctx = T.gemm_nn(dg, w_ih_d[:, E:])
             dh_prev = T.gemm_nn(dg, w_hh_d)
             if direct:      # the per-step slices start 16-byte aligned: the kernels write them in place
@@ -239,6 +237,7 @@ class BahdanauDecoderTrain(torch.autograd.Function):
             dh_next = dh_prev
         dG2 = dG.view(Tn * B, 4 * H)
         Hp2 = Hprev.view(Tn * B, H)
+        dEmb = T.gemm_nn(dG2, w_ih_e)              # no step needs it: one GEMM over all T*B rows after the loop
         dw_ih = torch.empty_like(w_ih)
         T.gemm_tn(dG2, emb_all, out=dw_ih[:, :E])
         T.gemm_tn(dG2, Ctx.view(Tn * B, ENC), out=dw_ih[:, E:])

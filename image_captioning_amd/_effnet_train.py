@@ -84,12 +84,15 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
     Ho, Wo = z1.shape[1], z1.shape[2]
     HW = Ho * Wo
     z1 = z1.view(B * HW, mid)
-    a1, bn1_bwd = _bn_act(tape, z1, blk._bn1, ACT_SWISH, st1)
+    # BatchNorm + swish of the depthwise result, with the squeeze-excite pooling taken by the same pass
+    bn1 = blk._bn1
+    a1, bn1_saved, pooled = T.batchnorm_train(z1, bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, bn1.eps,
+                                              bn1.momentum if bn1.momentum is not None else 0.1, act=ACT_SWISH, parts=st1, pool=(B, HW))
+    bn1.num_batches_tracked += 1
     # squeeze-excite
     sq = blk._se_reduce.weight.shape[0]
     wr, br = _w2d(blk._se_reduce), blk._se_reduce.bias.detach().float().contiguous()
     we, be = _w2d(blk._se_expand), blk._se_expand.bias.detach().float().contiguous()
-    pooled = T.image_dot(a1, None, B, HW, mid, scale=1.0 / HW)
     r_pre, e, gate = T.se_train_fwd(pooled, wr, br, we, be)          # reduce FC + swish + expand FC + sigmoid in one launch
     a2 = T.chan_affine(a1, gate, None, 0.0, B, HW, mid)
     z2, st2, proj_bwd = _conv1x1(tape, a2, blk._project_conv)
@@ -118,8 +121,10 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
         tape.grad(blk._se_expand.bias, dbe)
         tape.grad(blk._se_reduce.weight, dwr)
         tape.grad(blk._se_reduce.bias, dbr)
-        da1 = T.chan_affine(da2, gate, dpooled, 1.0 / HW, B, HW, mid)
-        dz1 = bn1_bwd(da1)
+        # the gate's and the pooled mean's gradients are applied to da2 inside the BatchNorm-gradient passes
+        dz1, dg1, db1 = T.batchnorm_act_bwd_se(da2, z1, bn1_saved, gate, dpooled, 1.0 / HW, HW, act=ACT_SWISH)
+        tape.grad(bn1.weight, dg1)
+        tape.grad(bn1.bias, db1)
         dww = T.dwconv_bwd_weight(dz1, a0, B, H, W, mid, k, stride, lo, lo, Ho, Wo)
         tape.grad(blk._depthwise_conv.weight, dww.t().contiguous().view(mid, 1, k, k))
         d = T.dwconv_bwd_data(dz1, dw_w, B, H, W, mid, k, stride, lo, lo, Ho, Wo)

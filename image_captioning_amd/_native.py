@@ -148,6 +148,9 @@ SIGNATURES = {
     "icap_chan_affine_f32": (_i, [_p, _p, _p, _f, _i, _i, _i, _p, _p]),
     "icap_image_dot_f32": (_i, [_p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "icap_image_dot_ws_floats": (_ll, [_i, _i, _i]),
+    "icap_act_pool_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
+    "icap_act_pool_ws_floats": (_ll, [_i, _i, _i]),
+    "icap_bn_act_bwd_se_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "icap_se_train_fwd_f32": (_i, [_p] * 8 + [_i, _i, _i, _p]),
     "icap_se_train_bwd_f32": (_i, [_p] * 13 + [_i, _i, _i, _p]),
     "icap_dwconv_bwd_data_f32": (_i, [_p, _p] + [_i] * 10 + [_p, _p]),

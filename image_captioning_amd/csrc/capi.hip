@@ -136,6 +136,10 @@ int embedding_bwd_f32(const long long*, const float*, int, int, int, int, float*
 int chan_affine_f32(const float*, const float*, const float*, float, int, int, int, float*, hipStream_t);
 int image_dot_f32(const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
 long long image_dot_ws_floats(int, int, int);
+int act_pool_f32(const float*, const float*, const float*, int, int, int, int, float, float*, float*, float*, hipStream_t);
+long long act_pool_ws_floats(int, int, int);
+int bn_act_bwd_se_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                      float, int, int, int, int, float*, float*, float*, float*, hipStream_t);
 
 int se_train_fwd_f32(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
                      hipStream_t);
@@ -783,6 +787,19 @@ int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, flo
     return image_dot_f32(x, y, B, HW, C, scale, out, ws, (hipStream_t)stream);
 }
 long long icap_image_dot_ws_floats(int B, int HW, int C) { return image_dot_ws_floats(B, HW, C); }
+
+int icap_act_pool_f32(const float* x, const float* s, const float* b, int act, int B, int HW, int C, float scale, float* y,
+                      float* pooled, float* ws, void* stream) {
+    return act_pool_f32(x, s, b, act, B, HW, C, scale, y, pooled, ws, (hipStream_t)stream);
+}
+
+long long icap_act_pool_ws_floats(int B, int HW, int C) { return act_pool_ws_floats(B, HW, C); }
+
+int icap_bn_act_bwd_se_f32(const float* dy, const float* x, const float* s, const float* b, const float* mean, const float* rstd,
+                           const float* gate, const float* dpool, float alpha, int HW, int act, int M, int C, float* dgamma,
+                           float* dbeta, float* dx, float* ws, void* stream) {
+    return bn_act_bwd_se_f32(dy, x, s, b, mean, rstd, gate, dpool, alpha, HW, act, M, C, dgamma, dbeta, dx, ws, (hipStream_t)stream);
+}
 
 int icap_se_train_fwd_f32(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* r_pre,
                           float* e, float* gate, int B, int C, int S, void* stream) {

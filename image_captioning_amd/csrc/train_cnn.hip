@@ -112,6 +112,98 @@ int image_dot_f32(const float* x, const float* y, int B, int HW, int C, float sc
     return launch_status("image_dot");
 }
 
+// y[b,p,c] = act(x[b,p,c] * s[c] + bi[c]) and out[b][c] = scale * sum_p y[b,p,c] in the same pass: the BatchNorm apply in
+// front of a squeeze-excite block and the block's global pooling.  Same thread layout and chunk partials as
+// image_dot_kernel; four row positions in flight per thread.
+template <int TX, int ACT>      // ACT >= 0: the activation fixed at compile time; < 0: the `act` argument
+__global__ __launch_bounds__(256) void act_pool_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                       const float* __restrict__ bi, int act, int HW, int C, int rows_per_chunk,
+                                                       float* __restrict__ y, float* __restrict__ part) {
+    constexpr int TY = 256 / TX, RU = 4;
+    __shared__ float4 red[TY][TX];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * 4;
+    const int chunk = blockIdx.y, nchunks = gridDim.y, b = blockIdx.z;
+    const int p_lo = chunk * rows_per_chunk, p_hi = min(HW, p_lo + rows_per_chunk);
+    const int a_ = ACT >= 0 ? ACT : act;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+        const float4 sv = *reinterpret_cast<const float4*>(s + c), bv = *reinterpret_cast<const float4*>(bi + c);
+        const size_t base = (size_t)b * HW * C + c;
+        for (int p = p_lo + ty; p < p_hi; p += RU * TY) {
+            float4 xv[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) xv[u] = *reinterpret_cast<const float4*>(x + base + (size_t)min(p + u * TY, p_hi - 1) * C);
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                if (p + u * TY >= p_hi) break;
+                const float4 v = make_float4(act_apply(fmaf(xv[u].x, sv.x, bv.x), a_), act_apply(fmaf(xv[u].y, sv.y, bv.y), a_),
+                                             act_apply(fmaf(xv[u].z, sv.z, bv.z), a_), act_apply(fmaf(xv[u].w, sv.w, bv.w), a_));
+                *reinterpret_cast<float4*>(y + base + (size_t)(p + u * TY) * C) = v;
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+        }
+    }
+    red[ty][tx] = sum;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float4 t = red[0][tx];
+        for (int k = 1; k < TY; ++k) { const float4 o = red[k][tx]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        *reinterpret_cast<float4*>(part + ((size_t)b * nchunks + chunk) * C + c) = t;
+    }
+}
+
+template <int ACT>
+static void act_pool_launch(int tx, dim3 grid, hipStream_t st, const float* x, const float* s, const float* b, int act, int HW, int C,
+                            int rows, float* y, float* ws) {
+    switch (tx) {
+        case 8: hipLaunchKernelGGL((act_pool_kernel<8, ACT>), grid, dim3(256), 0, st, x, s, b, act, HW, C, rows, y, ws); break;
+        case 16: hipLaunchKernelGGL((act_pool_kernel<16, ACT>), grid, dim3(256), 0, st, x, s, b, act, HW, C, rows, y, ws); break;
+        case 32: hipLaunchKernelGGL((act_pool_kernel<32, ACT>), grid, dim3(256), 0, st, x, s, b, act, HW, C, rows, y, ws); break;
+        default: hipLaunchKernelGGL((act_pool_kernel<64, ACT>), grid, dim3(256), 0, st, x, s, b, act, HW, C, rows, y, ws); break;
+    }
+}
+
+// channel-quad lanes per workgroup: the width among 8 / 16 / 32 / 64 with the fewest idle lanes in the last column block
+static int pool_tx(int c4) {
+    int best = 64, best_waste = 1 << 30;
+    for (int tx = 64; tx >= 8; tx >>= 1) {
+        const int waste = (c4 + tx - 1) / tx * tx - c4;
+        if (waste < best_waste) { best_waste = waste; best = tx; }
+    }
+    return best;
+}
+
+// rows of one image per workgroup: about 2048 workgroups in all, at least 32 rows each
+static int act_pool_rows(int B, int HW, int C) {
+    const int c4 = C / 4, tx = pool_tx(c4), col_blocks = (c4 + tx - 1) / tx;
+    long long want = 2048 / ((long long)B * col_blocks);
+    if (want < 1) want = 1;
+    long long rows = (HW + want - 1) / want;
+    if (rows < 32) rows = 32;
+    return (int)rows;
+}
+
+long long act_pool_ws_floats(int B, int HW, int C) {
+    const int rows = act_pool_rows(B, HW, C);
+    return (long long)B * ((HW + rows - 1) / rows) * C;
+}
+
+int act_pool_f32(const float* x, const float* s, const float* b, int act, int B, int HW, int C, float scale, float* y, float* out,
+                 float* ws, hipStream_t st) {
+    if (!x || !s || !b || !y || !out || !ws || B <= 0 || HW <= 0 || C <= 0) { set_error("act_pool: bad arguments"); return ICAP_ERR_ARG; }
+    if (C % 4 || !aligned16(x) || !aligned16(y) || !aligned16(s) || !aligned16(b) || !aligned16(ws)) {
+        set_error("act_pool: C %% 4 and 16-byte alignment required");
+        return ICAP_ERR_ALIGN;
+    }
+    const int rows = act_pool_rows(B, HW, C), nchunks = (HW + rows - 1) / rows, c4 = C / 4, tx = pool_tx(c4);
+    const dim3 grid((c4 + tx - 1) / tx, nchunks, B);
+    if (act == ACT_SWISH) act_pool_launch<ACT_SWISH>(tx, grid, st, x, s, b, act, HW, C, rows, y, ws);
+    else act_pool_launch<-1>(tx, grid, st, x, s, b, act, HW, C, rows, y, ws);
+    hipLaunchKernelGGL(image_dot_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, ws, nchunks, C, B * C, scale, out);
+    return launch_status("act_pool");
+}
+
 // ---------------------------------------------------------------- depthwise convolution, input gradient
 // dx[b,hi,wi,c] = sum over taps (r,q) with ho*S - pad_t + r == hi, wo*S - pad_l + q == wi of dy[b,ho,wo,c] * w[r*K+q][c]
 __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,

@@ -33,6 +33,23 @@ __device__ __forceinline__ float act_grad(float z, int act) {
     }
 }
 
+// A gradient that still has to pass a squeeze-excite gate on its way into a BatchNorm: the kernels that take this read
+//   a_eff[r][c] = a[r][c] * gate[r / HW][c] + add[r / HW][c] * alpha
+// (rows of one image share the gate; `add` is the pooled mean's gradient spread over the image) instead of a pass of its
+// own writing a_eff out.
+struct SeGate {
+    const float* gate = nullptr;
+    const float* add = nullptr;
+    float alpha = 0.f;
+    int HW = 1;
+};
+
+__device__ __forceinline__ float4 se_gated(float4 a, const SeGate& sg, unsigned row, unsigned c, unsigned C) {
+    const size_t o = (size_t)(row / (unsigned)sg.HW) * C + c;
+    const float4 g = *reinterpret_cast<const float4*>(sg.gate + o), d = *reinterpret_cast<const float4*>(sg.add + o);
+    return make_float4(fmaf(a.x, g.x, d.x * sg.alpha), fmaf(a.y, g.y, d.y * sg.alpha), fmaf(a.z, g.z, d.z * sg.alpha), fmaf(a.w, g.w, d.w * sg.alpha));
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, int lda, const float* __restrict__ x,
                                                           int ldx, const float* __restrict__ v1, const float* __restrict__ v2,
@@ -88,12 +105,12 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
 // meet in LDS in a fixed order.
 // ACT >= 0 fixes the activation of the BatchNorm-gradient mode at compile time (a run-time switch per element costs a
 // scalar branch tree around the transcendental instructions); ACT < 0 reads the `act` argument.
-template <int MODE, int TX, int ACT = -1>
+template <int MODE, int TX, int ACT = -1, bool GATED = false>
 __global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __restrict__ a, int lda, const float* __restrict__ x,
                                                               int ldx, const float* __restrict__ v1, const float* __restrict__ v2,
                                                               const float* __restrict__ v3, const float* __restrict__ v4,
                                                               const float* __restrict__ r1, const float* __restrict__ r2, int act,
-                                                              int M, int C, int rows_per_chunk, float* __restrict__ part) {
+                                                              int M, int C, int rows_per_chunk, float* __restrict__ part, SeGate sg) {
     constexpr int TY = 256 / TX;
     __shared__ float4 red[2][TY][TX];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -123,6 +140,7 @@ __global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __res
                     wt[u] = r + u * TY < r_hi ? 1.f : 0.f;
                     av[u] = *reinterpret_cast<const float4*>(a + (size_t)rr * lda + c);
                     xv[u] = *reinterpret_cast<const float4*>(x + (size_t)rr * ldx + c);
+                    if (GATED) av[u] = se_gated(av[u], sg, (unsigned)rr, (unsigned)c, (unsigned)C);
                 }
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
@@ -240,15 +258,15 @@ long long col_reduce_ws_floats(int M, int C) {
     return 2LL * (chunks_vec > chunks_scalar ? chunks_vec : chunks_scalar) * C;
 }
 
-template <int MODE, int ACT = -1>
+template <int MODE, int ACT = -1, bool GATED = false>
 static void col_launch_vec(int tx, dim3 grid, hipStream_t st, const float* a, int lda, const float* x, int ldx, const float* v1,
                            const float* v2, const float* v3, const float* v4, const float* r1, const float* r2, int act, int M, int C,
-                           int rpc, float* ws) {
+                           int rpc, float* ws, SeGate sg = SeGate{}) {
     switch (tx) {
-        case 8: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 8, ACT>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
-        case 16: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 16, ACT>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
-        case 32: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 32, ACT>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
-        default: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 64, ACT>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws); break;
+        case 8: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 8, ACT, GATED>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws, sg); break;
+        case 16: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 16, ACT, GATED>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws, sg); break;
+        case 32: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 32, ACT, GATED>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws, sg); break;
+        default: hipLaunchKernelGGL((col_partial_vec_kernel<MODE, 64, ACT, GATED>), grid, dim3(256), 0, st, a, lda, x, ldx, v1, v2, v3, v4, r1, r2, act, M, C, rpc, ws, sg); break;
     }
 }
 
@@ -646,12 +664,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
 // row), so the per-channel parameters are loaded once, and it keeps BWD_U row positions - 2 x BWD_U 16-byte loads - in flight.
 constexpr int BWD_U = 4;
 
-template <int ACT>      // >= 0: the activation fixed at compile time; < 0: the `act` argument decides per element
+template <int ACT, bool GATED = false>      // ACT >= 0: the activation fixed at compile time; < 0: the `act` argument decides per element
 __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ s, const float* __restrict__ b,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                             int act, int M, int C4, float* __restrict__ dx, int ldo) {
+                                                             int act, int M, int C4, float* __restrict__ dx, int ldo, SeGate sg) {
     const float inv_m = 1.0f / (float)M;
     const unsigned gtid = blockIdx.x * 256u + threadIdx.x;
     const unsigned stride = gridDim.x * 256u;                 // a multiple of C4 (the launcher sees to it)
@@ -678,6 +696,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const float* __rest
             const unsigned rr = min(r + u * row_step, (unsigned)M - 1u);     // clamped: every load is issued before the first use
             xq[u] = *reinterpret_cast<const float4*>(x + (size_t)rr * ldx + c);
             dq[u] = *reinterpret_cast<const float4*>(dy + (size_t)rr * ldd + c);
+            if (GATED) dq[u] = se_gated(dq[u], sg, rr, c, (unsigned)C4 * 4u);
         }
 #pragma unroll
         for (int u = 0; u < BWD_U; ++u) {
@@ -717,19 +736,55 @@ int bn_act_bwd_f32(const float* dy, int ldd, const float* x, int ldx, const floa
         vb = (vb + mult - 1) / mult * mult;
         if (act == ACT_SWISH)
             hipLaunchKernelGGL(bn_act_bwd_vec_kernel<ACT_SWISH>, dim3((unsigned)vb), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma,
-                               dbeta, act, M, C / 4, dx, ldo);
+                               dbeta, act, M, C / 4, dx, ldo, SeGate{});
         else if (act == ACT_NONE)
             hipLaunchKernelGGL(bn_act_bwd_vec_kernel<ACT_NONE>, dim3((unsigned)vb), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma,
-                               dbeta, act, M, C / 4, dx, ldo);
+                               dbeta, act, M, C / 4, dx, ldo, SeGate{});
         else
             hipLaunchKernelGGL(bn_act_bwd_vec_kernel<-1>, dim3((unsigned)vb), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma, dbeta,
-                               act, M, C / 4, dx, ldo);
+                               act, M, C / 4, dx, ldo, SeGate{});
         return launch_status("bn_act_bwd");
     }
     long long blocks = ((long long)M * C + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, ldd, x, ldx, s, b, mean, rstd, dgamma, dbeta, act, M, C, dx, ldo);
     return launch_status("bn_act_bwd");
+}
+
+// Gradient of y = act(BatchNorm_train(x)) when the incoming gradient still has to pass the squeeze-excite gate:
+//   dy_eff[b,p,c] = dy[b,p,c] * gate[b][c] + dpool[b][c] * alpha        (rows = B images of HW positions, dense [M][C])
+// Both passes (the two column sums, then dx) read dy and apply the gate on the fly; dy_eff is never written.
+// dgamma / dbeta [C] are results.  ws: col_reduce_ws_floats(M, C) floats.
+int bn_act_bwd_se_f32(const float* dy, const float* x, const float* s, const float* b, const float* mean, const float* rstd,
+                      const float* gate, const float* dpool, float alpha, int HW, int act, int M, int C, float* dgamma, float* dbeta,
+                      float* dx, float* ws, hipStream_t st) {
+    if (!dy || !x || !s || !b || !mean || !rstd || !gate || !dpool || !dgamma || !dbeta || !dx || !ws || M <= 0 || C <= 0 || HW <= 0 || M % HW) {
+        set_error("bn_act_bwd_se: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (!vec4_ok(M, C, {C}, {dy, x, dx, s, b, mean, rstd, gate, dpool, dgamma, dbeta, ws})) {
+        set_error("bn_act_bwd_se: C %% 4 == 0, fewer than 2^31 channel quads and 16-byte aligned operands required");
+        return ICAP_ERR_ALIGN;
+    }
+    const SeGate sg{gate, dpool, alpha, HW};
+    const int c4 = C / 4, tx = col_vec_tx(c4), rpc = col_rows_per_chunk(M, C), nchunks = (M + rpc - 1) / rpc;
+    const dim3 grid((c4 + tx - 1) / tx, nchunks);
+    if (act == ACT_SWISH) col_launch_vec<COL_BN_BWD, ACT_SWISH, true>(tx, grid, st, dy, C, x, C, mean, rstd, s, b, nullptr, nullptr, act, M, C, rpc, ws, sg);
+    else col_launch_vec<COL_BN_BWD, -1, true>(tx, grid, st, dy, C, x, C, mean, rstd, s, b, nullptr, nullptr, act, M, C, rpc, ws, sg);
+    hipLaunchKernelGGL(col_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, st, ws, nchunks, C, 2, 1.0f, 0, dbeta, dgamma);
+    int gcd = c4, t256 = 256;
+    while (t256) { const int t = gcd % t256; gcd = t256; t256 = t; }
+    const long long mult = c4 / gcd;
+    long long vb = ((long long)M * c4 + 256LL * BWD_U * 4 - 1) / (256LL * BWD_U * 4);
+    if (vb > 16384) vb = 16384;
+    vb = (vb + mult - 1) / mult * mult;
+    if (act == ACT_SWISH)
+        hipLaunchKernelGGL((bn_act_bwd_vec_kernel<ACT_SWISH, true>), dim3((unsigned)vb), dim3(256), 0, st, dy, C, x, C, s, b, mean, rstd, dgamma, dbeta,
+                           act, M, c4, dx, C, sg);
+    else
+        hipLaunchKernelGGL((bn_act_bwd_vec_kernel<-1, true>), dim3((unsigned)vb), dim3(256), 0, st, dy, C, x, C, s, b, mean, rstd, dgamma, dbeta,
+                           act, M, c4, dx, C, sg);
+    return launch_status("bn_act_bwd_se");
 }
 
 // ---------------------------------------------------------------- elementwise helpers

@@ -119,11 +119,13 @@ def col_sum(a, out=None, accumulate=False, scale=1.0):
     return col_reduce(COL_SUM, a, out1=out, accumulate=accumulate, scale=scale)[0]
 
 
-def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NONE, res=None, out=None, parts=None):
+def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NONE, res=None, out=None, parts=None, pool=None):
     """BatchNorm over the rows of x [M, C] with batch statistics (+ activation, + residual); updates the running
     statistics in place.  Returns (y, saved) with saved = (mean, rstd, s, b) for the backward pass.
     parts (ops.StatParts): the column statistics the kernel that produced x left behind - the pass over x that would
-    otherwise take them is skipped."""
+    otherwise take them is skipped.
+    pool = (B, HW): the rows are B images of HW positions and the per-image channel means of y are wanted too (taken by
+    the pass that writes y); returns (y, saved, pooled [B, C])."""
     _ckr(x, "x")
     M, C = x.shape
     dev = x.device
@@ -134,6 +136,9 @@ def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NO
         N.check(lib.icap_bn_stats_from_parts_f32(parts.part.data_ptr(), _p(parts.cnt), parts.P, parts.rows_per_part, M, C, _p(gamma), _p(beta),
                                                  float(eps), float(momentum), mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), b.data_ptr(),
                                                  _p(run_mean), _p(run_var), ws.data_ptr(), _stream()), "bn_stats_from_parts")
+        if pool is not None:
+            y, pooled = act_pool(x, s, b, act, pool[0], pool[1])
+            return y, (mean, rstd, s, b), pooled
         y = scale_bias_act(x, s, b, act=act, res=res, out=out)
         return y, (mean, rstd, s, b)
     # one pass over x: moments about its first row (a sample of every column, so the subtraction stays benign); the second
@@ -146,6 +151,9 @@ def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NO
                                         mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), b.data_ptr(), _p(run_mean), _p(run_var),
                                         ws.data_ptr(), _stream()), "bn_train_stats")
     span.done()
+    if pool is not None:
+        y, pooled = act_pool(x, s, b, act, pool[0], pool[1])
+        return y, (mean, rstd, s, b), pooled
     y = scale_bias_act(x, s, b, act=act, res=res, out=out)
     return y, (mean, rstd, s, b)
 
@@ -160,6 +168,43 @@ def scale_bias_act(x, s=None, b=None, act=ACT_NONE, res=None, out=None):
                                              act, M, C, out.data_ptr(), out.stride(0), _stream()), "scale_bias_act")
     span.done()
     return out
+
+
+def act_pool(x, s, b, act, B, HW):
+    """y = act(x * s + b) over x [B*HW, C] and the per-image channel means of y, in one pass -> (y, pooled [B, C])."""
+    _ckr(x, "x")
+    M, C = x.shape
+    if M != B * HW or not x.is_contiguous():
+        raise N.IcapError("act_pool: x must be a dense [B*HW, C] matrix")
+    lib = N.load()
+    y = torch.empty(M, C, device=x.device, dtype=torch.float32)
+    pooled = torch.empty(B, C, device=x.device, dtype=torch.float32)
+    ws = _ws(lib.icap_act_pool_ws_floats(B, HW, C), x.device)
+    span = _Span("act_pool", (B, HW, C))
+    N.check(lib.icap_act_pool_f32(x.data_ptr(), s.data_ptr(), b.data_ptr(), act, B, HW, C, 1.0 / HW, y.data_ptr(), pooled.data_ptr(),
+                                  ws.data_ptr(), _stream()), "act_pool")
+    span.done()
+    return y, pooled
+
+
+def batchnorm_act_bwd_se(dy, x, saved, gate, dpool, alpha, HW, act=ACT_NONE):
+    """batchnorm_act_bwd for a gradient that still has to pass a squeeze-excite gate: the gradient used is
+    dy * gate[image] + dpool[image] * alpha, formed inside the two passes.  Returns (dx, dgamma, dbeta)."""
+    mean, rstd, s, b = saved
+    M, C = x.shape
+    if not (dy.is_contiguous() and x.is_contiguous() and tuple(dy.shape) == (M, C)):
+        raise N.IcapError("batchnorm_act_bwd_se: dense [M, C] operands required")
+    lib = N.load()
+    dev = x.device
+    dx = torch.empty(M, C, device=dev, dtype=torch.float32)
+    dgamma = torch.empty(C, device=dev, dtype=torch.float32); dbeta = torch.empty(C, device=dev, dtype=torch.float32)
+    ws = _ws(lib.icap_col_reduce_ws_floats(M, C), dev)
+    span = _Span("bn_act_bwd_se", (M, C))
+    N.check(lib.icap_bn_act_bwd_se_f32(dy.data_ptr(), x.data_ptr(), s.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       gate.data_ptr(), dpool.data_ptr(), float(alpha), HW, act, M, C, dgamma.data_ptr(), dbeta.data_ptr(),
+                                       dx.data_ptr(), ws.data_ptr(), _stream()), "bn_act_bwd_se")
+    span.done()
+    return dx, dgamma, dbeta
 
 
 def batchnorm_act_bwd(dy, x, saved, act=ACT_NONE, affine=True):

@@ -596,6 +596,21 @@ int icap_chan_affine_f32(const float* x, const float* g, const float* a, float a
 int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, float* ws,
                        void* stream);
 long long icap_image_dot_ws_floats(int B, int HW, int C);
+/* The BatchNorm apply in front of a squeeze-excite block together with the block's pooling (efficientnet_pytorch MBConvBlock:
+ * _bn1 -> swish -> adaptive_avg_pool2d, train mode under transformer_word_level_bahdnau.py:12-25), one pass instead of two:
+ * y[b,p,c] = act(x[b,p,c] * s[c] + b[c]), pooled[b][c] = scale * sum_p y[b,p,c].  C % 4 == 0, 16-byte aligned operands
+ * (error 2 otherwise).  ws: icap_act_pool_ws_floats(B, HW, C) floats.  The sums are taken in a fixed order. */
+int icap_act_pool_f32(const float* x, const float* s, const float* b, int act, int B, int HW, int C, float scale, float* y,
+                      float* pooled, float* ws, void* stream);
+long long icap_act_pool_ws_floats(int B, int HW, int C);
+/* Gradient of y = act(BatchNorm_train(x)) when the arriving gradient still has to pass the squeeze-excite gate (same lines,
+ * backward): dy_eff[b,p,c] = dy[b,p,c] * gate[b][c] + dpool[b][c] * alpha is formed on the fly by both passes (the two column
+ * sums dgamma / dbeta [C], then dx) and never written out.  x, dy, dx dense [B*HW][C]; gate, dpool [B][C]; s, b, mean, rstd:
+ * what the forward pass kept.  C % 4 == 0 and 16-byte aligned operands (error 2 otherwise).
+ * ws: icap_col_reduce_ws_floats(B*HW, C) floats. */
+int icap_bn_act_bwd_se_f32(const float* dy, const float* x, const float* s, const float* b, const float* mean,
+                           const float* rstd, const float* gate, const float* dpool, float alpha, int HW, int act, int M,
+                           int C, float* dgamma, float* dbeta, float* dx, float* ws, void* stream);
 
 /* The squeeze-excite branch of an MBConv block in training mode (efficientnet_pytorch MBConvBlock: _se_reduce -> swish ->
  * _se_expand -> sigmoid, under transformer_word_level_bahdnau.py:12-25 in model.train()), one launch forward and two backward

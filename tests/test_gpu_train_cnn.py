@@ -48,6 +48,60 @@ def test_channel_affine_and_image_dot():
     torch.testing.assert_close(d, (x.view(B, HW, C) * y.view(B, HW, C)).sum(1), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,HW,C", [(3, 49, 32), (5, 196, 144), (2, 3136, 24), (4, 50, 1152), (7, 33, 40)])
+def test_act_pool_matches_separate_passes(B, HW, C):
+    """BatchNorm apply + swish + per-image mean in one pass against torch on the same numbers."""
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd.ops import ACT_NONE, ACT_SWISH
+    x, s, b = rnd(B * HW, C, seed=7), rnd(C, seed=8), rnd(C, seed=9)
+    for act, fn in ((ACT_SWISH, F.silu), (ACT_NONE, lambda v: v)):
+        y, pooled = T.act_pool(x.to(D), s.to(D), b.to(D), act, B, HW)
+        want = fn(x.double() * s.double() + b.double())
+        torch.testing.assert_close(y.cpu().double(), want, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(pooled.cpu().double(), want.view(B, HW, C).mean(1), rtol=1e-5, atol=1e-6)
+        y2, pooled2 = T.act_pool(x.to(D), s.to(D), b.to(D), act, B, HW)
+        assert torch.equal(pooled, pooled2) and torch.equal(y, y2)             # fixed summation order
+
+
+@pytest.mark.parametrize("B,HW,C", [(3, 49, 32), (5, 196, 144), (2, 3136, 24), (4, 50, 1152), (9, 33, 40)])
+def test_gated_batchnorm_gradient_matches_the_two_step_form(B, HW, C):
+    """The squeeze-excite gate applied inside the BatchNorm-gradient passes against chan_affine followed by the plain
+    BatchNorm gradient (same kernels, the gated tensor written out), and against torch autograd in float64."""
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd.ops import ACT_SWISH
+    M = B * HW
+    x, dy = rnd(M, C, seed=1), rnd(M, C, seed=2)
+    gate, dpool = torch.sigmoid(rnd(B, C, seed=3)), rnd(B, C, seed=4)
+    gamma, beta = rnd(C, seed=5) + 1.5, rnd(C, seed=6)
+    eps = 1e-3
+    y, saved = T.batchnorm_train(x.to(D), gamma.to(D), beta.to(D), None, None, eps, 0.1, act=ACT_SWISH)
+    dx, dg, db = T.batchnorm_act_bwd_se(dy.to(D), x.to(D), saved, gate.to(D), dpool.to(D), 1.0 / HW, HW, act=ACT_SWISH)
+    eff = T.chan_affine(dy.to(D), gate.to(D), dpool.to(D), 1.0 / HW, B, HW, C)
+    dx2, dg2, db2 = T.batchnorm_act_bwd(eff, x.to(D), saved, act=ACT_SWISH)
+    torch.testing.assert_close(dx, dx2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dg, dg2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(db, db2, rtol=1e-5, atol=1e-5)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = F.silu(F.batch_norm(xr, None, None, gr, br, True, 0.1, eps))
+    eff_r = dy.double().view(B, HW, C) * gate.double()[:, None, :] + dpool.double()[:, None, :] / HW
+    yr.backward(eff_r.view(M, C))
+    torch.testing.assert_close(dx.cpu().double(), xr.grad, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(dg.cpu().double(), gr.grad, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(db.cpu().double(), br.grad, rtol=2e-3, atol=2e-3)
+
+
+def test_act_pool_and_gated_gradient_argument_errors():
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd.ops import ACT_SWISH, IcapError
+    x = rnd(6, 6, seed=1).to(D)                                            # 6 channels: not a multiple of 4
+    v = rnd(6, seed=2).to(D)
+    with pytest.raises(IcapError):
+        T.act_pool(x, v, v, ACT_SWISH, 2, 3)
+    with pytest.raises(IcapError):
+        T.act_pool(rnd(8, 8, seed=1).to(D), rnd(8, seed=2).to(D), rnd(8, seed=2).to(D), ACT_SWISH, 3, 3)     # 8 rows are not 3 x 3
+
+
 def _cnn():
     from image_captioning_amd.backbones import get_cnn_model
     from image_captioning_amd.synthetic import seeded_state_dict

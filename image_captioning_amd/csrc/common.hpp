@@ -38,6 +38,13 @@ __device__ __forceinline__ float sigmoid_fast(float v) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 
+// tanh for the additive-attention scores (batch x batch x width evaluations per decode step, three times that in a training
+// step): 1 - 2 / (exp(2v) + 1) on the hardware exp2 and reciprocal, absolute error about 2e-7 (the libm tanhf is ~30
+// instructions with two paths); saturates to +-1 through exp2 -> inf / 0.
+__device__ __forceinline__ float tanh_fast(float v) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case ACT_RELU: return v > 0.f ? v : 0.f;

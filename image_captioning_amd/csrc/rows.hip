@@ -436,7 +436,7 @@ __global__ __launch_bounds__(BAH_THREADS) void bahdanau_attention_kernel(
                 uv[q] = u[(size_t)(j < B ? j : j0) * A + a];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s[q] = fmaf(aw, tanhf(uv[q] + wa), s[q]);
+            for (int q = 0; q < 4; ++q) s[q] = fmaf(aw, tanh_fast(uv[q] + wa), s[q]);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

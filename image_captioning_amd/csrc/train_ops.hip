@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_bwd_query_kernel(const float*
             const float wi = w[(size_t)i * A + a];
 #pragma unroll 8
             for (int j = jlo; j < jhi; ++j) {
-                const float th = tanhf(u[(size_t)j * A + a] + wi);
+                const float th = tanh_fast(u[(size_t)j * A + a] + wi);
                 accw += ds[j] * (1.f - th * th);
                 acca += ds[j] * th;
             }
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_bwd_key_kernel(const float* _
             const float uj = u[(size_t)j * A + a];
 #pragma unroll 8
             for (int i = ilo; i < ihi; ++i) {
-                const float th = tanhf(uj + w[(size_t)i * A + a]);
+                const float th = tanh_fast(uj + w[(size_t)i * A + a]);
                 acc += dsj[i] * (1.f - th * th);
             }
         }

@@ -166,8 +166,10 @@ def test_additive_attention_gradient(B):
     du = torch.zeros(B, A, device=D); dfeat = torch.zeros(B, E, device=D)
     dw, da_part, dab_part = T.attention_bwd(u.detach().to(D), w.detach().to(D), a_w.detach().to(D), alpha_g, feat.detach().to(D),
                                             dctx.to(D), du, dfeat, accumulate=False)
-    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-3, atol=1e-6)
-    torch.testing.assert_close(du.cpu(), u.grad, rtol=1e-3, atol=1e-6)
+    # the kernels' tanh (hardware exp2 + reciprocal) is within 2e-7 absolute of torch's: a sum of B terms
+    # dscore * a_w * (1 - th^2) that cancels to ~1e-4 can then sit 1-2e-6 from the float32 autograd value
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-3, atol=3e-6)
+    torch.testing.assert_close(du.cpu(), u.grad, rtol=1e-3, atol=3e-6)
     torch.testing.assert_close(dfeat.cpu(), feat.grad, rtol=1e-3, atol=1e-6)
     torch.testing.assert_close(da_part.sum(0).cpu(), a_w.grad, rtol=1e-3, atol=1e-5)
     # softmax is shift invariant: the exact gradient of the scoring bias is 0, both sides hold rounding noise

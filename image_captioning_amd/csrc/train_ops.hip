@@ -26,8 +26,8 @@ enum ColMode : int {
 __device__ __forceinline__ float act_grad(float z, int act) {
     switch (act) {
         case ACT_RELU: return z > 0.f ? 1.f : 0.f;
-        case ACT_SWISH: { const float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
-        case ACT_SIGMOID: { const float s = sigmoidf_(z); return s * (1.f - s); }
+        case ACT_SWISH: { const float s = sigmoid_fast(z); return s * (1.f + z * (1.f - s)); }
+        case ACT_SIGMOID: { const float s = sigmoid_fast(z); return s * (1.f - s); }
         case ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
         default: return 1.f;
     }

@@ -129,6 +129,9 @@ WORK = {"linear_f32x3": linear_x3_work, "linear_bf16": lambda s: linear_bf16_wor
         "bn_act_bwd": lambda s: (8.0 * s[0] * s[1], 4.0 * s[0] * s[1] * 3),
         # both passes of the gated form: the sums read dy and x, the apply reads them again and writes dx
         "bn_act_bwd_se": lambda s: (18.0 * s[0] * s[1], 4.0 * s[0] * s[1] * 5),
+        # BatchNorm1d of every decode step: statistics pass + apply; gradient sums + apply
+        "bn_steps_fwd": lambda s: (6.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * 3),
+        "bn_steps_bwd": lambda s: (12.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * 5),
         "act_pool": lambda s: (3.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * 2),
         "chan_affine": lambda s: (2.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * (2 if s[3] else 1)),
         "se_train_fwd": lambda s: (4.0 * s[0] * s[1] * s[2], 4.0 * (3 * s[0] * s[1] + 2 * s[1] * s[2])),

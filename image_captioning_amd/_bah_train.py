@@ -173,12 +173,16 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         out = torch.empty(B, Tn, V, device=dev)
         bn = mod.fc[1]
         mom = bn.momentum if bn.momentum is not None else 0.1
-        bn_saved = []
-        for t in range(Tn):
-            x_t = pre[t * B:(t + 1) * B]
-            # one pass over the step's rows (moments about the first row), the running statistics updated in step order
-            _, saved = T.batchnorm_train(x_t, bn_g, bn_b, bn.running_mean, bn.running_var, bn.eps, mom, out=out[:, t, :])
-            bn_saved.append(saved)
+        if V % 4 == 0:
+            # every step normalised with the statistics of its own B rows, all steps per launch
+            bn_saved = T.batchnorm_steps_fwd(pre, bn_g.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.eps, mom, B, Tn, out)
+        else:
+            bn_saved = []
+            for t in range(Tn):
+                x_t = pre[t * B:(t + 1) * B]
+                # one pass over the step's rows (moments about the first row), the running statistics updated in step order
+                _, saved = T.batchnorm_train(x_t, bn_g, bn_b, bn.running_mean, bn.running_var, bn.eps, mom, out=out[:, t, :])
+                bn_saved.append(saved)
         bn.num_batches_tracked += Tn
         ctx.saved = (feats, idx, emb_all, w_ih_e, w_ih_c, u, a_w, Hprev, Cs, Ws, Al, Ctx, G, hd, m_out, pre, bn_saved)
         ctx.params = (W_w, U_w, w_ih, w_hh, fc_w, emb_w)
@@ -194,10 +198,13 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         A = u.shape[1]
         dout = dout.float().contiguous()
         # BatchNorm1d(V) of every step
-        dpre = torch.empty(Tn * B, V, device=dev)
-        DG = torch.empty(Tn, V, device=dev); DB = torch.empty(Tn, V, device=dev)     # per-step dgamma / dbeta, summed after the loop
         lib = T.N.load()
-        for t in range(Tn):
+        if not isinstance(bn_saved, list):
+            dpre, DG, DB = T.batchnorm_steps_bwd(dout, pre, bn_saved, B, Tn)
+        else:
+            dpre = torch.empty(Tn * B, V, device=dev)
+            DG = torch.empty(Tn, V, device=dev); DB = torch.empty(Tn, V, device=dev)     # per-step dgamma / dbeta, summed after the loop
+        for t in range(Tn if isinstance(bn_saved, list) else 0):
             mean, rstd, s, b = bn_saved[t]
             dy_t = dout[:, t, :]
             x_t = pre[t * B:(t + 1) * B]

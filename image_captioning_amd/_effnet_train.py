@@ -28,6 +28,7 @@ class _Tape:
     def __init__(self):
         self.steps = []
         self.grads = {}
+        self.counters = []         # num_batches_tracked of every BatchNorm passed: bumped together when the forward ends
 
     def add(self, fn):
         self.steps.append(fn)
@@ -46,7 +47,7 @@ def _bn_act(tape, z, bn, act, parts=None):
     mom = bn.momentum if bn.momentum is not None else 0.1
     y, saved = T.batchnorm_train(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, mom, act=act,
                                  parts=parts)
-    bn.num_batches_tracked += 1
+    tape.counters.append(bn.num_batches_tracked)
 
     def bwd(dy):
         dx, dg, db = T.batchnorm_act_bwd(dy, z, saved, act=act)
@@ -88,7 +89,7 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
     bn1 = blk._bn1
     a1, bn1_saved, pooled = T.batchnorm_train(z1, bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, bn1.eps,
                                               bn1.momentum if bn1.momentum is not None else 0.1, act=ACT_SWISH, parts=st1, pool=(B, HW))
-    bn1.num_batches_tracked += 1
+    tape.counters.append(bn1.num_batches_tracked)
     # squeeze-excite
     sq = blk._se_reduce.weight.shape[0]
     wr, br = _w2d(blk._se_reduce), blk._se_reduce.bias.detach().float().contiguous()
@@ -190,6 +191,8 @@ class CnnTrain(torch.autograd.Function):
         # the closures hold the tape (for tape.grad); the tape must not hold them back, or a step's activations would
         # sit in a reference cycle until Python's cycle collector happens to run
         ctx.steps, tape.steps = tape.steps, None
+        torch._foreach_add_(tape.counters, 1)
+        tape.counters = []
         ctx.tape = tape
         ctx.params = params
         return out

@@ -137,6 +137,10 @@ int chan_affine_f32(const float*, const float*, const float*, float, int, int, i
 int image_dot_f32(const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
 long long image_dot_ws_floats(int, int, int);
 int act_pool_f32(const float*, const float*, const float*, int, int, int, int, float, float*, float*, float*, hipStream_t);
+int bn_steps_fwd_f32(const float*, const float*, const float*, float, float, int, int, int, float*, float*, float*, float*, float*,
+                     float*, float*, float*, hipStream_t);
+int bn_steps_bwd_f32(const float*, const float*, const float*, const float*, const float*, int, int, int, float*, float*, float*,
+                     hipStream_t);
 long long act_pool_ws_floats(int, int, int);
 int bn_act_bwd_se_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                       float, int, int, int, int, float*, float*, float*, float*, hipStream_t);
@@ -787,6 +791,17 @@ int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, flo
     return image_dot_f32(x, y, B, HW, C, scale, out, ws, (hipStream_t)stream);
 }
 long long icap_image_dot_ws_floats(int B, int HW, int C) { return image_dot_ws_floats(B, HW, C); }
+
+int icap_bn_steps_fwd_f32(const float* x, const float* gamma, const float* beta, float eps, float momentum, int B, int T, int V,
+                          float* y, float* mean, float* rstd, float* s, float* b, float* uvar, float* run_mean, float* run_var,
+                          void* stream) {
+    return bn_steps_fwd_f32(x, gamma, beta, eps, momentum, B, T, V, y, mean, rstd, s, b, uvar, run_mean, run_var, (hipStream_t)stream);
+}
+
+int icap_bn_steps_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* s, int B, int T, int V,
+                          float* dgamma_t, float* dbeta_t, float* dx, void* stream) {
+    return bn_steps_bwd_f32(dy, x, mean, rstd, s, B, T, V, dgamma_t, dbeta_t, dx, (hipStream_t)stream);
+}
 
 int icap_act_pool_f32(const float* x, const float* s, const float* b, int act, int B, int HW, int C, float scale, float* y,
                       float* pooled, float* ws, void* stream) {

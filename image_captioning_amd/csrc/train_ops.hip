@@ -751,6 +751,214 @@ int bn_act_bwd_f32(const float* dy, int ldd, const float* x, int ldx, const floa
     return launch_status("bn_act_bwd");
 }
 
+// ---------------------------------------------------------------- BatchNorm1d of every decode step, all steps per launch
+// The teacher-forced Bahdanau decoder normalises the V logits of each time step with the statistics of that step's B rows.
+// x [T*B][V] is step-major (rows t*B ... t*B + B - 1 belong to step t); y / dy are [B][T][V], the layout the loss reads.
+// One workgroup owns 256 columns of one step: 64 channel-quad lanes x 4 row lanes, four rows in flight per thread, the row
+// lanes meet in LDS in a fixed order.  Per-step launches of the plain kernels are bound by launch latency at these sizes
+// (6.9 MB per step at B = 256, V = 6756).
+constexpr int BNS_TX = 64, BNS_TY = 4, BNS_RU = 4;
+
+__global__ __launch_bounds__(256) void bn_steps_stats_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int B, int V,
+                                                             float* __restrict__ mean, float* __restrict__ rstd,
+                                                             float* __restrict__ s, float* __restrict__ b, float* __restrict__ uvar) {
+    __shared__ float4 red[2][BNS_TY][BNS_TX];
+    const int tx = threadIdx.x % BNS_TX, ty = threadIdx.x / BNS_TX;
+    const int c = (blockIdx.x * BNS_TX + tx) * 4, t = blockIdx.y;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, sh = s1;
+    if (c < V) {
+        const float* base = x + (size_t)t * B * V + c;
+        sh = *reinterpret_cast<const float4*>(base);                   // moments about the step's first row
+        for (int r = ty; r < B; r += BNS_TY * BNS_RU) {
+            float4 v[BNS_RU];
+#pragma unroll
+            for (int u = 0; u < BNS_RU; ++u) v[u] = *reinterpret_cast<const float4*>(base + (size_t)min(r + u * BNS_TY, B - 1) * V);
+#pragma unroll
+            for (int u = 0; u < BNS_RU; ++u) {
+                if (r + u * BNS_TY >= B) break;
+                const float d0 = v[u].x - sh.x, d1 = v[u].y - sh.y, d2 = v[u].z - sh.z, d3 = v[u].w - sh.w;
+                s1.x += d0; s1.y += d1; s1.z += d2; s1.w += d3;
+                s2.x = fmaf(d0, d0, s2.x); s2.y = fmaf(d1, d1, s2.y); s2.z = fmaf(d2, d2, s2.z); s2.w = fmaf(d3, d3, s2.w);
+            }
+        }
+    }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < V) {
+        float a1[4], a2[4];
+        {
+            float4 p = red[0][0][tx], q = red[1][0][tx];
+            for (int k = 1; k < BNS_TY; ++k) {
+                const float4 o = red[0][k][tx], w = red[1][k][tx];
+                p.x += o.x; p.y += o.y; p.z += o.z; p.w += o.w;
+                q.x += w.x; q.y += w.y; q.z += w.z; q.w += w.w;
+            }
+            a1[0] = p.x; a1[1] = p.y; a1[2] = p.z; a1[3] = p.w;
+            a2[0] = q.x; a2[1] = q.y; a2[2] = q.z; a2[3] = q.w;
+        }
+        const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float4 g4 = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 b4 = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        float mu[4], rs[4], sc[4], bi[4], uv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mu[k] = shv[k] + a1[k] / (float)B;
+            const float sq = fmaxf(a2[k] - a1[k] * a1[k] / (float)B, 0.f);
+            const float var = sq / (float)B;
+            rs[k] = 1.0f / sqrtf(var + eps);
+            sc[k] = gv[k] * rs[k];
+            bi[k] = bv[k] - mu[k] * gv[k] * rs[k];
+            uv[k] = B > 1 ? sq / (float)(B - 1) : var;
+        }
+        const size_t o = (size_t)t * V + c;
+        *reinterpret_cast<float4*>(mean + o) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+        *reinterpret_cast<float4*>(rstd + o) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+        *reinterpret_cast<float4*>(s + o) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+        *reinterpret_cast<float4*>(b + o) = make_float4(bi[0], bi[1], bi[2], bi[3]);
+        *reinterpret_cast<float4*>(uvar + o) = make_float4(uv[0], uv[1], uv[2], uv[3]);
+    }
+}
+
+// running statistics: one momentum update per step, in step order
+__global__ __launch_bounds__(256) void bn_steps_running_kernel(const float* __restrict__ mean, const float* __restrict__ uvar,
+                                                               float momentum, int T, int V, float* __restrict__ run_mean,
+                                                               float* __restrict__ run_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= V) return;
+    float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 0.f;
+    for (int t = 0; t < T; ++t) {
+        rm = (1.f - momentum) * rm + momentum * mean[(size_t)t * V + c];
+        rv = (1.f - momentum) * rv + momentum * uvar[(size_t)t * V + c];
+    }
+    if (run_mean) run_mean[c] = rm;
+    if (run_var) run_var[c] = rv;
+}
+
+// y[r][t][:] = x[t*B + r][:] * s[t][:] + b[t][:]
+__global__ __launch_bounds__(256) void bn_steps_apply_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                             const float* __restrict__ b, int B, int T, int V4,
+                                                             float* __restrict__ y) {
+    const unsigned total = (unsigned)T * (unsigned)B * (unsigned)V4;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned row = i / (unsigned)V4, c4 = i - row * (unsigned)V4;
+        const unsigned t = row / (unsigned)B, r = row - t * (unsigned)B;
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 sv = reinterpret_cast<const float4*>(s)[(size_t)t * V4 + c4], bv = reinterpret_cast<const float4*>(b)[(size_t)t * V4 + c4];
+        reinterpret_cast<float4*>(y)[((size_t)r * T + t) * V4 + c4] =
+            make_float4(fmaf(xv.x, sv.x, bv.x), fmaf(xv.y, sv.y, bv.y), fmaf(xv.z, sv.z, bv.z), fmaf(xv.w, sv.w, bv.w));
+    }
+}
+
+// dbeta_t[t][c] = sum_r dy[r][t][c],  dgamma_t[t][c] = sum_r dy[r][t][c] * xhat[t*B + r][c]
+__global__ __launch_bounds__(256) void bn_steps_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                int B, int T, int V, float* __restrict__ dgamma_t,
+                                                                float* __restrict__ dbeta_t) {
+    __shared__ float4 red[2][BNS_TY][BNS_TX];
+    const int tx = threadIdx.x % BNS_TX, ty = threadIdx.x / BNS_TX;
+    const int c = (blockIdx.x * BNS_TX + tx) * 4, t = blockIdx.y;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (c < V) {
+        const float* xb = x + (size_t)t * B * V + c;
+        const float* db = dy + (size_t)t * V + c;
+        const float4 m = *reinterpret_cast<const float4*>(mean + (size_t)t * V + c), rs = *reinterpret_cast<const float4*>(rstd + (size_t)t * V + c);
+        for (int r = ty; r < B; r += BNS_TY * BNS_RU) {
+            float4 xv[BNS_RU], dv[BNS_RU];
+#pragma unroll
+            for (int u = 0; u < BNS_RU; ++u) {
+                const int rr = min(r + u * BNS_TY, B - 1);
+                xv[u] = *reinterpret_cast<const float4*>(xb + (size_t)rr * V);
+                dv[u] = *reinterpret_cast<const float4*>(db + (size_t)rr * T * V);
+            }
+#pragma unroll
+            for (int u = 0; u < BNS_RU; ++u) {
+                if (r + u * BNS_TY >= B) break;
+                s1.x += dv[u].x; s1.y += dv[u].y; s1.z += dv[u].z; s1.w += dv[u].w;
+                s2.x += dv[u].x * ((xv[u].x - m.x) * rs.x); s2.y += dv[u].y * ((xv[u].y - m.y) * rs.y);
+                s2.z += dv[u].z * ((xv[u].z - m.z) * rs.z); s2.w += dv[u].w * ((xv[u].w - m.w) * rs.w);
+            }
+        }
+    }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < V) {
+        float4 p = red[0][0][tx], q = red[1][0][tx];
+        for (int k = 1; k < BNS_TY; ++k) {
+            const float4 o = red[0][k][tx], w = red[1][k][tx];
+            p.x += o.x; p.y += o.y; p.z += o.z; p.w += o.w;
+            q.x += w.x; q.y += w.y; q.z += w.z; q.w += w.w;
+        }
+        *reinterpret_cast<float4*>(dbeta_t + (size_t)t * V + c) = p;
+        *reinterpret_cast<float4*>(dgamma_t + (size_t)t * V + c) = q;
+    }
+}
+
+// dx[t*B + r][c] = s[t][c] * (dy[r][t][c] - dbeta_t[t][c] / B - xhat * dgamma_t[t][c] / B)
+__global__ __launch_bounds__(256) void bn_steps_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ s, const float* __restrict__ dgamma_t,
+                                                                 const float* __restrict__ dbeta_t, int B, int T, int V4,
+                                                                 float* __restrict__ dx) {
+    const unsigned total = (unsigned)T * (unsigned)B * (unsigned)V4;
+    const float inv_b = 1.0f / (float)B;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned row = i / (unsigned)V4, c4 = i - row * (unsigned)V4;
+        const unsigned t = row / (unsigned)B, r = row - t * (unsigned)B;
+        const size_t o = (size_t)t * V4 + c4;
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 dv = reinterpret_cast<const float4*>(dy)[((size_t)r * T + t) * V4 + c4];
+        const float4 m = reinterpret_cast<const float4*>(mean)[o], rs = reinterpret_cast<const float4*>(rstd)[o];
+        const float4 sv = reinterpret_cast<const float4*>(s)[o];
+        const float4 dg = reinterpret_cast<const float4*>(dgamma_t)[o], db = reinterpret_cast<const float4*>(dbeta_t)[o];
+        reinterpret_cast<float4*>(dx)[i] = make_float4(sv.x * (dv.x - db.x * inv_b - (xv.x - m.x) * rs.x * dg.x * inv_b),
+                                                       sv.y * (dv.y - db.y * inv_b - (xv.y - m.y) * rs.y * dg.y * inv_b),
+                                                       sv.z * (dv.z - db.z * inv_b - (xv.z - m.z) * rs.z * dg.z * inv_b),
+                                                       sv.w * (dv.w - db.w * inv_b - (xv.w - m.w) * rs.w * dg.w * inv_b));
+    }
+}
+
+static bool bn_steps_ok(int B, int T, int V, std::initializer_list<const void*> ptrs) {
+    if (V % 4 || (long long)B * T * (V / 4) >= (1LL << 31)) return false;
+    for (const void* p : ptrs) if (p && !aligned16(p)) return false;
+    return true;
+}
+
+int bn_steps_fwd_f32(const float* x, const float* gamma, const float* beta, float eps, float momentum, int B, int T, int V, float* y,
+                     float* mean, float* rstd, float* s, float* b, float* uvar, float* run_mean, float* run_var, hipStream_t st) {
+    if (!x || !y || !mean || !rstd || !s || !b || !uvar || B <= 0 || T <= 0 || V <= 0) { set_error("bn_steps_fwd: bad arguments"); return ICAP_ERR_ARG; }
+    if (!bn_steps_ok(B, T, V, {x, y, gamma, beta, mean, rstd, s, b, uvar})) {
+        set_error("bn_steps_fwd: V %% 4 == 0, fewer than 2^31 channel quads and 16-byte aligned operands required");
+        return ICAP_ERR_ALIGN;
+    }
+    const int V4 = V / 4;
+    hipLaunchKernelGGL(bn_steps_stats_kernel, dim3((V4 + BNS_TX - 1) / BNS_TX, T), dim3(256), 0, st, x, gamma, beta, eps, B, V, mean, rstd, s, b, uvar);
+    if (run_mean || run_var)
+        hipLaunchKernelGGL(bn_steps_running_kernel, dim3((V + 255) / 256), dim3(256), 0, st, mean, uvar, momentum, T, V, run_mean, run_var);
+    long long blocks = ((long long)T * B * V4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bn_steps_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, s, b, B, T, V4, y);
+    return launch_status("bn_steps_fwd");
+}
+
+int bn_steps_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* s, int B, int T, int V,
+                     float* dgamma_t, float* dbeta_t, float* dx, hipStream_t st) {
+    if (!dy || !x || !mean || !rstd || !s || !dgamma_t || !dbeta_t || !dx || B <= 0 || T <= 0 || V <= 0) { set_error("bn_steps_bwd: bad arguments"); return ICAP_ERR_ARG; }
+    if (!bn_steps_ok(B, T, V, {dy, x, mean, rstd, s, dgamma_t, dbeta_t, dx})) {
+        set_error("bn_steps_bwd: V %% 4 == 0, fewer than 2^31 channel quads and 16-byte aligned operands required");
+        return ICAP_ERR_ALIGN;
+    }
+    const int V4 = V / 4;
+    hipLaunchKernelGGL(bn_steps_bwd_sums_kernel, dim3((V4 + BNS_TX - 1) / BNS_TX, T), dim3(256), 0, st, dy, x, mean, rstd, B, T, V, dgamma_t, dbeta_t);
+    long long blocks = ((long long)T * B * V4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bn_steps_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, x, mean, rstd, s, dgamma_t, dbeta_t, B, T, V4, dx);
+    return launch_status("bn_steps_bwd");
+}
+
 // Gradient of y = act(BatchNorm_train(x)) when the incoming gradient still has to pass the squeeze-excite gate:
 //   dy_eff[b,p,c] = dy[b,p,c] * gate[b][c] + dpool[b][c] * alpha        (rows = B images of HW positions, dense [M][C])
 // Both passes (the two column sums, then dx) read dy and apply the gate on the fly; dy_eff is never written.

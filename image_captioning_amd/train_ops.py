@@ -170,6 +170,40 @@ def scale_bias_act(x, s=None, b=None, act=ACT_NONE, res=None, out=None):
     return out
 
 
+def batchnorm_steps_fwd(x, gamma, beta, run_mean, run_var, eps, momentum, B, Tn, out):
+    """BatchNorm1d over the columns of x [Tn*B, V] (step-major) with the statistics of each step's own B rows, all steps in
+    one launch each; out [B, Tn, V] receives the result, the running statistics one momentum update per step in step
+    order.  Returns saved = (mean, rstd, s, b), each [Tn, V]."""
+    _ckr(x, "x")
+    V = x.shape[1]
+    if tuple(x.shape) != (Tn * B, V) or tuple(out.shape) != (B, Tn, V) or not (x.is_contiguous() and out.is_contiguous()):
+        raise N.IcapError("batchnorm_steps_fwd: x must be a dense [T*B, V] matrix and out a dense [B, T, V] tensor")
+    dev = x.device
+    mean, rstd, s, b, uvar = (torch.empty(Tn, V, device=dev, dtype=torch.float32) for _ in range(5))
+    span = _Span("bn_steps_fwd", (B, Tn, V))
+    N.check(N.load().icap_bn_steps_fwd_f32(x.data_ptr(), _p(gamma), _p(beta), float(eps), float(momentum), B, Tn, V, out.data_ptr(),
+                                           mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), b.data_ptr(), uvar.data_ptr(),
+                                           _p(run_mean), _p(run_var), _stream()), "bn_steps_fwd")
+    span.done()
+    return mean, rstd, s, b
+
+
+def batchnorm_steps_bwd(dy, x, saved, B, Tn):
+    """Gradient of batchnorm_steps_fwd: dy [B, Tn, V] -> (dx [Tn*B, V], dgamma_t [Tn, V], dbeta_t [Tn, V])."""
+    mean, rstd, s, _ = saved
+    V = x.shape[1]
+    if tuple(dy.shape) != (B, Tn, V) or not (dy.is_contiguous() and x.is_contiguous()):
+        raise N.IcapError("batchnorm_steps_bwd: dy must be a dense [B, T, V] tensor")
+    dev = x.device
+    dx = torch.empty(Tn * B, V, device=dev, dtype=torch.float32)
+    dg = torch.empty(Tn, V, device=dev, dtype=torch.float32); db = torch.empty(Tn, V, device=dev, dtype=torch.float32)
+    span = _Span("bn_steps_bwd", (B, Tn, V))
+    N.check(N.load().icap_bn_steps_bwd_f32(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), B, Tn, V,
+                                           dg.data_ptr(), db.data_ptr(), dx.data_ptr(), _stream()), "bn_steps_bwd")
+    span.done()
+    return dx, dg, db
+
+
 def act_pool(x, s, b, act, B, HW):
     """y = act(x * s + b) over x [B*HW, C] and the per-image channel means of y, in one pass -> (y, pooled [B, C])."""
     _ckr(x, "x")

@@ -531,6 +531,19 @@ int icap_bn_act_bwd_f32(const float* dy, int ldd, const float* x, int ldx, const
                         const float* mean, const float* rstd, const float* dgamma, const float* dbeta, int act, int M,
                         int C, float* dx, int ldo, void* stream);
 
+/* nn.BatchNorm1d(V) applied to the logits of every time step of a teacher-forced pass (transformer_word_level_bahdnau.py:139:
+ * self.fc holds Linear + BatchNorm1d and runs once per step, so each step is normalised with the statistics of its own B rows
+ * and the running statistics receive one momentum update per step, in step order), all T steps per launch.
+ * x [T*B][V] step-major (rows t*B ... t*B+B-1 = step t); y, dy [B][T][V]; mean, rstd, s, b, uvar, dgamma_t, dbeta_t [T][V]
+ * (uvar: scratch for the unbiased variances).  Forward writes y and the per-step mean / rstd / fused scale s and bias b the
+ * backward needs; backward returns dx [T*B][V] and the per-step parameter gradients (their sum over t is the layer's).
+ * V % 4 == 0 and 16-byte aligned operands (error 2 otherwise).  Sums in a fixed order. */
+int icap_bn_steps_fwd_f32(const float* x, const float* gamma, const float* beta, float eps, float momentum, int B, int T,
+                          int V, float* y, float* mean, float* rstd, float* s, float* b, float* uvar, float* run_mean,
+                          float* run_var, void* stream);
+int icap_bn_steps_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* s, int B,
+                          int T, int V, float* dgamma_t, float* dbeta_t, float* dx, void* stream);
+
 /* y = alpha*x + beta*y (gradient accumulation where a tensor feeds several consumers). */
 int icap_axpby_f32(const float* x, float alpha, float beta, float* y, long long n, void* stream);
 

@@ -211,3 +211,42 @@ def test_squeeze_excite_train_forward_backward(B, C, S):
     for got, want, name in ((dpooled, pooled.grad, "dpooled"), (dwe, we.grad, "dwe"), (dbe, be.grad, "dbe"), (dwr, wr.grad, "dwr"),
                             (dbr, br.grad, "dbr")):
         torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-5 * max(1.0, want.abs().max().item()), msg=lambda m: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("B,Tn,V", [(5, 3, 8), (12, 4, 300), (37, 2, 1028), (256, 3, 6756)])
+def test_batchnorm_of_every_step_in_one_launch(B, Tn, V):
+    """icap_bn_steps_fwd/bwd against torch's BatchNorm1d applied step by step (float64 autograd), running statistics included."""
+    from image_captioning_amd import train_ops as T
+    x = rnd(Tn * B, V, seed=31) * 2.0 + 0.5
+    gamma, beta = rnd(V, seed=32) + 1.5, rnd(V, seed=33)
+    rm0, rv0 = rnd(V, seed=34) * 0.1, torch.rand(V, generator=torch.Generator().manual_seed(35)) + 0.5
+    dy = rnd(B, Tn, V, seed=36)
+    eps, mom = 1e-5, 0.1
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    ys = [torch.nn.functional.batch_norm(xr[t * B:(t + 1) * B], rm, rv, gr, br, True, mom, eps) for t in range(Tn)]
+    want = torch.stack(ys, dim=1)                                            # [B, Tn, V]
+    want.backward(dy.double())
+    out = torch.empty(B, Tn, V, device=D)
+    rmg, rvg = rm0.to(D), rv0.to(D)
+    saved = T.batchnorm_steps_fwd(x.to(D), gamma.to(D), beta.to(D), rmg, rvg, eps, mom, B, Tn, out)
+    torch.testing.assert_close(out.cpu().double(), want.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rmg.cpu().double(), rm, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rvg.cpu().double(), rv, rtol=1e-4, atol=1e-6)
+    dx, dg_t, db_t = T.batchnorm_steps_bwd(dy.to(D), x.to(D), saved, B, Tn)
+    torch.testing.assert_close(dx.cpu().double(), xr.grad, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(dg_t.sum(0).cpu().double(), gr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(db_t.sum(0).cpu().double(), br.grad, rtol=1e-3, atol=1e-3)
+    # the same numbers as the step-by-step kernels the decoder used before
+    for t in range(Tn):
+        y_t, sv = T.batchnorm_train(x[t * B:(t + 1) * B].to(D), gamma.to(D), beta.to(D), None, None, eps, mom)
+        torch.testing.assert_close(out[:, t, :], y_t, rtol=1e-5, atol=1e-5)
+
+
+def test_batchnorm_steps_rejects_unaligned_width():
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd.ops import IcapError
+    out = torch.empty(4, 2, 6, device=D)
+    with pytest.raises(IcapError):
+        T.batchnorm_steps_fwd(rnd(8, 6, seed=1).to(D), None, None, None, None, 1e-5, 0.1, 4, 2, out)

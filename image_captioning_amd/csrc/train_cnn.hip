@@ -586,28 +586,42 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
-// one workgroup per image: r_pre = wr . pooled + br, e = we . swish(r_pre) + be, gate = sigmoid(e)
-__global__ __launch_bounds__(256) void se_train_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
-                                                           const float* __restrict__ br, const float* __restrict__ we,
-                                                           const float* __restrict__ be, float* __restrict__ r_pre,
-                                                           float* __restrict__ e, float* __restrict__ gate, int C, int S) {
+// one workgroup of SE_NT threads per image: r_pre = wr . pooled + br, e = we . swish(r_pre) + be, gate = sigmoid(e).
+// The problem is tiny and every phase is a chain of dependent memory round trips, so the time is set by how many loads one
+// image keeps in flight: sixteen waves, each taking its squeeze units two at a time.
+constexpr int SE_NT = 1024, SE_NW = SE_NT / 64;
+
+__global__ __launch_bounds__(SE_NT) void se_train_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
+                                                             const float* __restrict__ br, const float* __restrict__ we,
+                                                             const float* __restrict__ be, float* __restrict__ r_pre,
+                                                             float* __restrict__ e, float* __restrict__ gate, int C, int S) {
     __shared__ float pl[SET_MAX_C];
     __shared__ float sq[SET_MAX_S];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int c = tid; c < C; c += 256) pl[c] = pooled[(size_t)b * C + c];
+    for (int c = tid; c < C; c += SE_NT) pl[c] = pooled[(size_t)b * C + c];
     __syncthreads();
-    for (int j = wave; j < S; j += 4) {
-        float a = 0.f;
-#pragma unroll 8
-        for (int c = lane; c < C; c += 64) a = fmaf(wr[(size_t)j * C + c], pl[c], a);
-        a = wave_sum_f(a) + br[j];
+    for (int j = wave; j < S; j += 2 * SE_NW) {
+        const int j2 = j + SE_NW < S ? j + SE_NW : j;        // the second unit of this pass (a repeat of the first past the end)
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+        for (int c = lane; c < C; c += 64) {
+            const float p = pl[c];
+            a0 = fmaf(wr[(size_t)j * C + c], p, a0);
+            a1 = fmaf(wr[(size_t)j2 * C + c], p, a1);
+        }
+        a0 = wave_sum_f(a0) + br[j];
+        a1 = wave_sum_f(a1) + br[j2];
         if (lane == 0) {
-            r_pre[(size_t)b * S + j] = a;
-            sq[j] = a * sigmoid_fast(a);
+            r_pre[(size_t)b * S + j] = a0;
+            sq[j] = a0 * sigmoid_fast(a0);
+            if (j2 != j) {
+                r_pre[(size_t)b * S + j2] = a1;
+                sq[j2] = a1 * sigmoid_fast(a1);
+            }
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += SE_NT) {
         float a = be[c];
         const float* w = we + (size_t)c * S;
 #pragma unroll 8
@@ -618,28 +632,28 @@ __global__ __launch_bounds__(256) void se_train_fwd_kernel(const float* __restri
 }
 
 // one workgroup per image: de = dgate * sigmoid'(e); dr_pre = (we^T de) * swish'(r_pre); dpooled = wr^T dr_pre
-__global__ __launch_bounds__(256) void se_train_bwd_image_kernel(const float* __restrict__ dgate, const float* __restrict__ e,
+__global__ __launch_bounds__(SE_NT) void se_train_bwd_image_kernel(const float* __restrict__ dgate, const float* __restrict__ e,
                                                                  const float* __restrict__ r_pre, const float* __restrict__ wr,
                                                                  const float* __restrict__ we, float* __restrict__ de,
                                                                  float* __restrict__ dr_pre, float* __restrict__ dpooled, int C,
                                                                  int S) {
     __shared__ float dl[SET_MAX_C];
     __shared__ float dr[SET_MAX_S];
-    __shared__ float part2[4][SET_MAX_S];
+    __shared__ float part2[SE_NW][SET_MAX_S];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += SE_NT) {
         const float g = sigmoid_fast(e[(size_t)b * C + c]);
         const float d = dgate[(size_t)b * C + c] * g * (1.f - g);
         dl[c] = d;
         de[(size_t)b * C + c] = d;
     }
     __syncthreads();
-    // we^T de: a lane walks channels lane, lane + 64, ... of its wave's quarter and reads their rows of `we` contiguously
+    // we^T de: a lane walks channels lane, lane + 64, ... of its wave's share and reads their rows of `we` contiguously
     // (column-wise, one squeeze unit at a time, every lane touched a different cache line per load); the S partial sums of
-    // a wave meet in LDS and wave 0 adds the four quarters in order
+    // a wave meet in LDS and the first S threads add the waves' shares in order
     {
         constexpr int JB = 16;           // squeeze units per sweep over the channels
-        const int cq = (C + 3) / 4, c_lo = wave * cq, c_hi = min(C, c_lo + cq);
+        const int cq = (C + SE_NW - 1) / SE_NW, c_lo = min(C, wave * cq), c_hi = min(C, c_lo + cq);
         for (int j0 = 0; j0 < S; j0 += JB) {
             float acc[JB];
 #pragma unroll
@@ -660,14 +674,16 @@ __global__ __launch_bounds__(256) void se_train_bwd_image_kernel(const float* __
     __syncthreads();
     if (tid < S) {
         const int j = tid;
-        const float a = ((part2[0][j] + part2[1][j]) + part2[2][j]) + part2[3][j];
+        float a = part2[0][j];
+#pragma unroll
+        for (int k = 1; k < SE_NW; ++k) a += part2[k][j];
         const float x = r_pre[(size_t)b * S + j], sg = sigmoid_fast(x);
         const float d = a * sg * (1.f + x * (1.f - sg));
         dr[j] = d;
         dr_pre[(size_t)b * S + j] = d;
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += SE_NT) {
         float a = 0.f;
 #pragma unroll 8
         for (int j = 0; j < S; ++j) a = fmaf(wr[(size_t)j * C + c], dr[j], a);
@@ -771,7 +787,7 @@ int se_train_fwd_f32(const float* pooled, const float* wr, const float* br, cons
                      float* e, float* gate, int B, int C, int S, hipStream_t st) {
     if (!pooled || !wr || !br || !we || !be || !r_pre || !e || !gate) { set_error("se_train_fwd: null pointer"); return ICAP_ERR_ARG; }
     if (const int rc = se_train_args("se_train_fwd", B, C, S)) return rc;
-    hipLaunchKernelGGL(se_train_fwd_kernel, dim3(B), dim3(256), 0, st, pooled, wr, br, we, be, r_pre, e, gate, C, S);
+    hipLaunchKernelGGL(se_train_fwd_kernel, dim3(B), dim3(SE_NT), 0, st, pooled, wr, br, we, be, r_pre, e, gate, C, S);
     return launch_status("se_train_fwd");
 }
 
@@ -783,7 +799,7 @@ int se_train_bwd_f32(const float* dgate, const float* e, const float* r_pre, con
         return ICAP_ERR_ARG;
     }
     if (const int rc = se_train_args("se_train_bwd", B, C, S)) return rc;
-    hipLaunchKernelGGL(se_train_bwd_image_kernel, dim3(B), dim3(256), 0, st, dgate, e, r_pre, wr, we, de, dr_pre, dpooled, C, S);
+    hipLaunchKernelGGL(se_train_bwd_image_kernel, dim3(B), dim3(SE_NT), 0, st, dgate, e, r_pre, wr, we, de, dr_pre, dpooled, C, S);
     hipLaunchKernelGGL(se_train_bwd_weights_kernel, dim3((C + 63) / 64, (S + 15) / 16), dim3(256), 0, st, de, dr_pre, r_pre, pooled, dwe,
                        dbe, dwr, dbr, B, C, S);
     return launch_status("se_train_bwd");

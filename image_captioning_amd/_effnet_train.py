@@ -205,7 +205,7 @@ class CnnTrain(torch.autograd.Function):
             d = f(d)
         grads = tuple(tape.grads.get(id(p)) for p in ctx.params)
         tape.grads = {}
-        return (None, None, None) + grads
+        return (None, None, None) + T.accumulate_into_grads(ctx.params, grads)
 
 
 def cnn_train(model, images, masks=None):

@@ -590,6 +590,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // The problem is tiny and every phase is a chain of dependent memory round trips, so the time is set by how many loads one
 // image keeps in flight: sixteen waves, each taking its squeeze units two at a time.
 constexpr int SE_NT = 1024, SE_NW = SE_NT / 64;
+constexpr int SE_CL = 16, SE_NS = 256 / SE_CL;       // se_train_bwd_weights_kernel: channels and image slices per workgroup
 
 __global__ __launch_bounds__(SE_NT) void se_train_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
                                                              const float* __restrict__ br, const float* __restrict__ we,
@@ -691,18 +692,20 @@ __global__ __launch_bounds__(SE_NT) void se_train_bwd_image_kernel(const float* 
     }
 }
 
-// parameter gradients: a workgroup owns 64 channels x 16 squeeze units; its 256 threads are 64 channels x 4 image slices
-// (image b goes to slice b mod 4), each slice sums its images in order and the four slices are added in order
+// parameter gradients: a workgroup owns SE_CL channels x 16 squeeze units; its 256 threads are SE_CL channels x SE_NS image
+// slices (image b goes to slice b mod SE_NS), each slice sums its images in order and the slices are added in order.  Few
+// channels per workgroup on purpose: the loop over the images is a chain of memory round trips, so the launch wants many
+// workgroups (216 at C = 1152, S = 48) rather than wide ones
 __global__ __launch_bounds__(256) void se_train_bwd_weights_kernel(const float* __restrict__ de, const float* __restrict__ dr_pre,
                                                                    const float* __restrict__ r_pre, const float* __restrict__ pooled,
                                                                    float* __restrict__ dwe, float* __restrict__ dbe,
                                                                    float* __restrict__ dwr, float* __restrict__ dbr, int B, int C,
                                                                    int S) {
-    constexpr int SG = 16, BT = 256;
+    constexpr int SG = 16, BT = 256, CL = SE_CL, NS = SE_NS;
     __shared__ float rl[BT][SG], dl[BT][SG];
-    __shared__ float red[3][64][2 * SG + 1];
-    const int tid = threadIdx.x, cl = tid & 63, slice = tid >> 6;
-    const int c = blockIdx.x * 64 + cl, s0 = blockIdx.y * SG;
+    __shared__ float red[NS - 1][CL][2 * SG + 1];
+    const int tid = threadIdx.x, cl = tid % CL, slice = tid / CL;
+    const int c = blockIdx.x * CL + cl, s0 = blockIdx.y * SG;
     const bool ok = c < C;
     float awe[SG], awr[SG], sbe = 0.f;
 #pragma unroll
@@ -719,20 +722,20 @@ __global__ __launch_bounds__(256) void se_train_bwd_weights_kernel(const float* 
         __syncthreads();
         const int nb = min(BT, B - b0);
         // eight images of this slice per round, their loads issued before the first is used (one image at a time the loop is a
-        // chain of 64 memory round trips); images beyond the batch read a clamped address and count as zero
+        // chain of memory round trips); images beyond the batch read a clamped address and count as zero
         constexpr int IU = 8;
         const int cc = ok ? c : 0;
-        for (int bb = slice; bb < nb; bb += 4 * IU) {
+        for (int bb = slice; bb < nb; bb += NS * IU) {
             float dv[IU], pvv[IU];
 #pragma unroll
             for (int u = 0; u < IU; ++u) {
-                const int bi = min(bb + 4 * u, nb - 1);
+                const int bi = min(bb + NS * u, nb - 1);
                 dv[u] = de[(size_t)(b0 + bi) * C + cc];
                 pvv[u] = pooled[(size_t)(b0 + bi) * C + cc];
             }
 #pragma unroll
             for (int u = 0; u < IU; ++u) {
-                const int bi = bb + 4 * u;
+                const int bi = bb + NS * u;
                 if (bi >= nb) break;
                 const float d = ok ? dv[u] : 0.f, pv = ok ? pvv[u] : 0.f;
                 sbe += d;
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(256) void se_train_bwd_weights_kernel(const float* 
     }
     __syncthreads();
     if (slice == 0 && ok) {
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < NS - 1; ++k) {
 #pragma unroll
             for (int j = 0; j < SG; ++j) { awe[j] += red[k][cl][j]; awr[j] += red[k][cl][SG + j]; }
             sbe += red[k][cl][2 * SG];
@@ -800,7 +803,7 @@ int se_train_bwd_f32(const float* dgate, const float* e, const float* r_pre, con
     }
     if (const int rc = se_train_args("se_train_bwd", B, C, S)) return rc;
     hipLaunchKernelGGL(se_train_bwd_image_kernel, dim3(B), dim3(SE_NT), 0, st, dgate, e, r_pre, wr, we, de, dr_pre, dpooled, C, S);
-    hipLaunchKernelGGL(se_train_bwd_weights_kernel, dim3((C + 63) / 64, (S + 15) / 16), dim3(256), 0, st, de, dr_pre, r_pre, pooled, dwe,
+    hipLaunchKernelGGL(se_train_bwd_weights_kernel, dim3((C + SE_CL - 1) / SE_CL, (S + 15) / 16), dim3(256), 0, st, de, dr_pre, r_pre, pooled, dwe,
                        dbe, dwr, dbr, B, C, S);
     return launch_status("se_train_bwd");
 }

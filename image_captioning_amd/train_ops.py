@@ -31,6 +31,29 @@ def _ws(n: int, dev) -> torch.Tensor | None:
     return torch.empty(max(int(n), 1), device=dev, dtype=torch.float32) if n > 0 else None
 
 
+def accumulate_into_grads(params, grads):
+    """Adds grads[i] into params[i].grad for every parameter that already holds a gradient buffer of the same shape - ONE
+    multi-tensor add instead of autograd's one small add per parameter (213 of them for the EfficientNet) - and then runs
+    the parameters' post-accumulate hooks, as autograd would have.  Returns the gradients still to be handed to autograd:
+    None where the sum was taken here, grads[i] elsewhere (no buffer yet, other shape or dtype)."""
+    dst, src, idx = [], [], []
+    for i, (p, g) in enumerate(zip(params, grads)):
+        if g is None or p.grad is None or p.grad.shape != g.shape or p.grad.dtype != g.dtype or p.grad.device != g.device:
+            continue
+        dst.append(p.grad); src.append(g); idx.append(i)
+    if not dst:
+        return tuple(grads)
+    torch._foreach_add_(dst, src)
+    left = list(grads)
+    for i in idx:
+        left[i] = None
+        hooks = getattr(params[i], "_post_accumulate_grad_hooks", None)
+        if hooks:
+            for h in list(hooks.values()):
+                h(params[i])
+    return tuple(left)
+
+
 def transpose(a: torch.Tensor) -> torch.Tensor:
     """[R, C] (rows may be strided) -> dense [C, R]."""
     _ckr(a, "a")

@@ -77,8 +77,17 @@ __global__ __launch_bounds__(256) void image_dot_finish_kernel(const float* __re
     const int i = blockIdx.x * 256 + threadIdx.x;   // b * C + c
     if (i >= total) return;
     const int b = i / C, c = i - b * C;
+    // sixteen chunk partials in flight at a time (one at a time the loop is a chain of nchunks memory round trips), added in
+    // chunk order
     float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += part[((size_t)b * nchunks + k) * C + c];
+    const float* src = part + (size_t)b * nchunks * C + c;
+    for (int k0 = 0; k0 < nchunks; k0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(size_t)min(k0 + u, nchunks - 1) * C];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += k0 + u < nchunks ? v[u] : 0.f;
+    }
     out[i] = s * scale;
 }
 

@@ -63,6 +63,11 @@ def transpose(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# rows from which gemm_nn goes through the tile kernel of ops.linear (one launch, split-K inside) rather than the generic
+# backward kernel + its split-K reduction
+GEMM_NN_TILE_MIN_ROWS = 8
+
+
 def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False,
             add: torch.Tensor | None = None) -> torch.Tensor:
     """out[M, N] (+)= a[M, K] @ b[K, N]  (input gradient of a Linear: dX = dY @ W).  add [M, N]: a second gradient flowing
@@ -75,7 +80,7 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, a
     if add is not None:
         if out is not None or accumulate or tuple(add.shape) != (M, Nn) or not add.is_contiguous():
             raise N.IcapError("gemm_nn: `add` needs a fresh result and a contiguous [M, N] tensor")
-        if K % 4 == 0 and Nn % 4 == 0 and a.stride(0) == K and M >= 64:
+        if K % 4 == 0 and Nn % 4 == 0 and a.stride(0) == K and M >= GEMM_NN_TILE_MIN_ROWS:
             bt = ops.step_cached("transposed", b, lambda: transpose(b))
             return ops.linear(a, bt, residual=add)
         return axpby(add, gemm_nn(a, b))
@@ -83,7 +88,7 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, a
         out = torch.empty(M, Nn, device=a.device, dtype=torch.float32)
         accumulate = False
     lib = N.load()
-    if K % 4 == 0 and Nn % 4 == 0 and a.stride(0) == K and out.stride(0) == Nn and M >= 64:
+    if K % 4 == 0 and Nn % 4 == 0 and a.stride(0) == K and out.stride(0) == Nn and M >= GEMM_NN_TILE_MIN_ROWS:
         # the tuned implicit-GEMM kernel wants the contraction axis of both operands contiguous: a transposed copy of the
         # (small) second operand buys its 60-100 TFLOP/s instead of the k-major staging of the generic backward kernel
         # (inside a training step the copy is made once per weight, not once per time step)

@@ -157,8 +157,8 @@ class CnnTrain(torch.autograd.Function):
 
         def stem_bwd(da):
             dz = bn0_bwd(da)
-            col = T.im2col(x4, B, H, W, 4, 3, 3, 2, lo, lo, Ho, Wo)                    # [M, 36]
-            dw = T.gemm_tn(dz, col).view(32, 3, 3, 4)[:, :, :, :3].permute(0, 3, 1, 2).contiguous()
+            # patches gathered from the image inside the GEMM: [32, (kh, kw, c)] -> the parameter's [32, c, kh, kw]
+            dw = T.conv_wgrad_gather(dz, x4, B, H, W, 4, 3, 3, 3, 2, lo, lo, Ho, Wo).view(32, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
             tape.grad(eff._conv_stem.weight, dw)
             return None
         tape.add(stem_bwd)

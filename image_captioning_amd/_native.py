@@ -166,6 +166,8 @@ SIGNATURES = {
     "icap_augment_ws_bytes": (C.c_longlong, [_i]),
     "icap_augment_u8": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "icap_resize_normalize_u8_f32": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
+    "icap_conv_wgrad_gather_f32": (_i, [_p, _i, _p] + [_i] * 13 + [_p, _p, _p]),
+    "icap_conv_wgrad_gather_ws_floats": (_ll, [_i, _i, _i, _i, _i]),
     "icap_im2col_f32": (_i, [_p] + [_i] * 11 + [_p, _p]),
 }
 

@@ -154,6 +154,9 @@ int dwconv_bwd_weight_f32(const float*, const float*, int, int, int, int, int, i
 long long dwconv_bwd_weight_ws_floats(int, int, int, int, int);
 int transpose_f32(const float*, int, int, int, float*, hipStream_t);
 int im2col_f32(const float*, int, int, int, int, int, int, int, int, int, int, int, float*, hipStream_t);
+int conv_wgrad_gather_f32(const float*, int, const float*, int, int, int, int, int, int, int, int, int, int, int, int, int, float*, float*,
+                          hipStream_t);
+long long conv_wgrad_gather_ws_floats(int, int, int, int, int);
 
 static inline long long align4(long long n) { return (n + 3) & ~3LL; }
 
@@ -872,6 +875,13 @@ int icap_resize_normalize_u8_f32(const unsigned char* src, int B, int H, int W, 
 int icap_transpose_f32(const float* src, int rows, int cols, int ld_src, float* dst, void* stream) {
     return transpose_f32(src, rows, cols, ld_src, dst, (hipStream_t)stream);
 }
+
+int icap_conv_wgrad_gather_f32(const float* dz, int ldz, const float* x, int B, int H, int W, int C, int Cv, int KH, int KW, int S,
+                               int pad_t, int pad_l, int Ho, int Wo, int Cout, float* dw, float* ws, void* stream) {
+    return conv_wgrad_gather_f32(dz, ldz, x, B, H, W, C, Cv, KH, KW, S, pad_t, pad_l, Ho, Wo, Cout, dw, ws, (hipStream_t)stream);
+}
+
+long long icap_conv_wgrad_gather_ws_floats(int B, int Ho, int Wo, int Cout, int N) { return conv_wgrad_gather_ws_floats(B, Ho, Wo, Cout, N); }
 
 int icap_im2col_f32(const float* x, int B, int H, int W, int C, int KH, int KW, int S, int pad_t, int pad_l, int Ho, int Wo, float* col,
                     void* stream) {

@@ -477,6 +477,103 @@ static void skinny_launch(const float* a, int lda, const float* b, int ldb, int 
     hipLaunchKernelGGL((gemm_tn_skinny_kernel<MB, NB>), grid, dim3(256), 0, st, a, lda, b, ldb, K, M, N, rpw, ws);
 }
 
+// ---------------------------------------------------------------- weight gradient of a few-channel convolution (the stem)
+// dW[co][(r*KW + q)*Cv + c] = sum_m dz[m][co] * x[b, ho*S - pad_t + r, wo*S - pad_l + q, c],  m = (b*Ho + ho)*Wo + wo, c < Cv <= C
+// (C: stored channels per pixel, Cv: the real ones).  It is the skinny TN form with the second operand GATHERED from the
+// image: no patch matrix is written and read back (for the 3-channel 3x3 stride-2 stem at B = 256 that matrix is 460 MB
+// against 205 MB of image).  Cout <= 32 and KH*KW*Cv <= 32: one MFMA block per wave.  A lane's column fixes its tap and
+// channel; its row's (b, ho, wo) comes from one division per batch of rows and is stepped from there.
+__global__ __launch_bounds__(256) void conv_wgrad_gather_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ x,
+                                                                int H, int W, int C, int Cv, int KW, int S, int pad_t, int pad_l,
+                                                                int Ho, int Wo, int K, int M, int N, int rows_per_wave,
+                                                                float* __restrict__ part) {
+    __shared__ float tile[32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int chunk = blockIdx.x;
+    const int r_lo = (chunk * 4 + wave) * rows_per_wave;
+    const int r_hi = min(K, r_lo + rows_per_wave);
+    f32x16s acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const bool a_ok = lr < M, b_ok = lr < N;
+    const int a_col = a_ok ? lr : 0;
+    const int n = b_ok ? lr : 0, tap = n / Cv, c = n - tap * Cv, kr = tap / KW, kq = tap - kr * KW;
+    const int dr = kr - pad_t, dq = kq - pad_l;
+    for (int r = r_lo; r < r_hi; r += 2 * SK_U) {
+        const int row0 = r + lh;
+        int wo = row0 % Wo;
+        const int t = row0 / Wo;
+        int ho = t % Ho, b = t / Ho;
+        float av[SK_U], bv[SK_U];
+#pragma unroll
+        for (int u = 0; u < SK_U; ++u) {
+            const int row = r + 2 * u + lh;
+            const bool ok = row < r_hi;
+            const int hi = ho * S + dr, wi = wo * S + dq;
+            const bool inb = ok && b_ok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+            const size_t xo = inb ? (((size_t)b * H + hi) * W + wi) * C + c : 0;      // always a valid address
+            av[u] = dz[(size_t)(ok ? row : r_lo) * ldz + a_col];
+            bv[u] = x[xo];
+            if (!(ok && a_ok)) av[u] = 0.f;
+            if (!inb) bv[u] = 0.f;
+            wo += 2;
+            while (wo >= Wo) {
+                wo -= Wo;
+                if (++ho >= Ho) { ho = 0; ++b; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SK_U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    // the four waves meet in LDS in wave order (a lane holds column lr and rows (e&3) + 8*(e>>2) + 4*lh of the block)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float& tv = tile[(e & 3) + 8 * (e >> 2) + 4 * lh][lr];
+                tv = (w == 0 ? 0.f : tv) + acc[e];
+            }
+        }
+        __syncthreads();
+    }
+    float* dst = part + (size_t)chunk * M * N;
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+        const int mi = idx >> 5, ni = idx & 31;
+        if (mi < M && ni < N) dst[(size_t)mi * N + ni] = tile[mi][ni];
+    }
+}
+
+long long conv_wgrad_gather_ws_floats(int B, int Ho, int Wo, int M, int N) {
+    const long long K = (long long)B * Ho * Wo;
+    if (K <= 0 || K >= (1LL << 31) || M <= 0 || N <= 0) return 0;
+    return (long long)skinny_chunks((int)K, 1) * M * N;
+}
+
+int conv_wgrad_gather_f32(const float* dz, int ldz, const float* x, int B, int H, int W, int C, int Cv, int KH, int KW, int S,
+                          int pad_t, int pad_l, int Ho, int Wo, int Cout, float* dw, float* ws, hipStream_t st) {
+    if (!dz || !x || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Cv <= 0 || Cv > C || KH <= 0 || KW <= 0 || S <= 0 || Ho <= 0 ||
+        Wo <= 0 || Cout <= 0 || ldz < Cout || pad_t < 0 || pad_l < 0) {
+        set_error("conv_wgrad_gather: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    const int N = KH * KW * Cv;
+    const long long K = (long long)B * Ho * Wo;
+    if (Cout > 32 || N > 32 || K >= (1LL << 31)) {
+        set_error("conv_wgrad_gather: Cout %d and KH*KW*Cv %d must be <= 32 (patch matrix + icap_gemm_bwd_f32 otherwise)", Cout, N);
+        return ICAP_ERR_LIMIT;
+    }
+    // the last output position must read inside the padded extent the forward pass used
+    if ((long long)(Ho - 1) * S - pad_t >= H || (long long)(Wo - 1) * S - pad_l >= W) { set_error("conv_wgrad_gather: output larger than the input allows"); return ICAP_ERR_ARG; }
+    const int chunks = skinny_chunks((int)K, 1);
+    int rpw = (int)((K + chunks * 4 - 1) / (chunks * 4));
+    rpw = (rpw + 1) & ~1;                                   // row pairs must not straddle two waves
+    hipLaunchKernelGGL(conv_wgrad_gather_kernel, dim3(chunks), dim3(256), 0, st, dz, ldz, x, H, W, C, Cv, KW, S, pad_t, pad_l, Ho, Wo, (int)K,
+                       Cout, N, rpw, ws);
+    hipLaunchKernelGGL(gemm_tn_finish_kernel, dim3((Cout * N + 7) / 8), dim3(256), 0, st, ws, chunks, Cout, N, dw, N, 0);
+    return launch_status("conv_wgrad_gather");
+}
+
 // ---------------------------------------------------------------- short contraction (the reference's loader batch of 12)
 // TN, K <= 16:  C[M][N] (+)= A[K][M]^T . B[K][N] - a sum of K outer products; a thread owns one row and four columns
 template <int KR>

@@ -490,6 +490,24 @@ def dwconv_bwd_weight(dy, x, B, H, W, C, K, S, pad_t, pad_l, Ho, Wo):
     return dw
 
 
+def conv_wgrad_gather(dz, x, B, H, W, C, Cv, KH, KW, S, pad_t, pad_l, Ho, Wo):
+    """Weight gradient of a few-channel convolution (the stem) without a patch matrix: dz [B*Ho*Wo, Cout], x [B, H, W, C]
+    with Cv real channels -> dw [Cout, KH*KW*Cv] (tap-major, channel fastest).  Cout and KH*KW*Cv at most 32."""
+    _ckr(dz, "dz")
+    Cout = dz.shape[1]
+    if dz.shape[0] != B * Ho * Wo or x.numel() != B * H * W * C or not x.is_contiguous():
+        raise N.IcapError("conv_wgrad_gather: dz must be [B*Ho*Wo, Cout] and x a dense [B, H, W, C] tensor")
+    lib = N.load()
+    Nn = KH * KW * Cv
+    dw = torch.empty(Cout, Nn, device=x.device, dtype=torch.float32)
+    ws = _ws(max(lib.icap_conv_wgrad_gather_ws_floats(B, Ho, Wo, Cout, Nn), 1), x.device)
+    span = _Span("conv_wgrad_gather", (B, H, W, C, Cv, KH, S, Ho, Wo, Cout))
+    N.check(lib.icap_conv_wgrad_gather_f32(dz.data_ptr(), dz.stride(0), x.data_ptr(), B, H, W, C, Cv, KH, KW, S, pad_t, pad_l, Ho, Wo, Cout,
+                                           dw.data_ptr(), ws.data_ptr(), _stream()), "conv_wgrad_gather")
+    span.done()
+    return dw
+
+
 def im2col(x, B, H, W, C, KH, KW, S, pad_t, pad_l, Ho, Wo):
     col = torch.empty(B * Ho * Wo, KH * KW * C, device=x.device, dtype=torch.float32)
     N.check(N.load().icap_im2col_f32(x.data_ptr(), B, H, W, C, KH, KW, S, pad_t, pad_l, Ho, Wo, col.data_ptr(), _stream()), "im2col")

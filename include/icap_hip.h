@@ -679,6 +679,15 @@ int icap_resize_normalize_u8_f32(const unsigned char* src, int B, int H, int W, 
 int icap_im2col_f32(const float* x, int B, int H, int W, int C, int KH, int KW, int S, int pad_t, int pad_l, int Ho,
                     int Wo, float* col, void* stream);
 
+/* Weight gradient of a convolution with few input channels, the 3-channel 3x3 stride-2 stem of get_cnn_model
+ * (transformer_word_level_bahdnau.py:12-25, trained end to end), without a patch matrix: the patches are gathered from the
+ * image inside the GEMM.  x [B][H][W][C] (C stored channels of which the first Cv are real), dz [B*Ho*Wo][Cout] (row stride
+ * ldz); dw [Cout][(r*KW+q)*Cv + c].  Cout <= 32 and KH*KW*Cv <= 32 (error 3 otherwise: icap_im2col_f32 + icap_gemm_bwd_f32
+ * cover the general case).  ws: icap_conv_wgrad_gather_ws_floats floats.  Partial sums are added in a fixed order. */
+int icap_conv_wgrad_gather_f32(const float* dz, int ldz, const float* x, int B, int H, int W, int C, int Cv, int KH, int KW,
+                               int S, int pad_t, int pad_l, int Ho, int Wo, int Cout, float* dw, float* ws, void* stream);
+long long icap_conv_wgrad_gather_ws_floats(int B, int Ho, int Wo, int Cout, int N);
+
 #ifdef __cplusplus
 }
 #endif

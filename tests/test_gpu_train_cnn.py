@@ -102,6 +102,41 @@ def test_act_pool_and_gated_gradient_argument_errors():
         T.act_pool(rnd(8, 8, seed=1).to(D), rnd(8, seed=2).to(D), rnd(8, seed=2).to(D), ACT_SWISH, 3, 3)     # 8 rows are not 3 x 3
 
 
+@pytest.mark.parametrize("B,H,W,Cout,K,S", [(2, 224, 224, 32, 3, 2), (3, 17, 23, 32, 3, 2), (2, 16, 16, 24, 3, 1), (5, 9, 9, 8, 1, 1), (1, 225, 225, 32, 3, 2)])
+def test_stem_weight_gradient_without_patch_matrix(B, H, W, Cout, K, S):
+    """icap_conv_wgrad_gather_f32 against torch autograd (float64) and against the patch-matrix path it replaces."""
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd.backbones import same_pad
+    lo, hi = same_pad(K, S) if K > 1 else (0, 0)
+    x = rnd(B, 3, H, W, seed=1)
+    w = rnd(Cout, 3, K, K, seed=2).double().requires_grad_(True)
+    y = F.conv2d(F.pad(x.double(), (lo, hi, lo, hi)), w, stride=S)
+    Ho, Wo = y.shape[2], y.shape[3]
+    dy = rnd(B, Cout, Ho, Wo, seed=3)
+    y.backward(dy.double())
+    x4 = torch.zeros(B, H, W, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    dz = dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout).contiguous()
+    dw = T.conv_wgrad_gather(dz.to(D), x4.to(D), B, H, W, 4, 3, K, K, S, lo, lo, Ho, Wo)
+    got = dw.view(Cout, K, K, 3).permute(0, 3, 1, 2).cpu().double()
+    scale = float(w.grad.abs().max())
+    assert float((got - w.grad).abs().max()) <= 2e-5 * scale + 1e-5
+    col = T.im2col(x4.to(D), B, H, W, 4, K, K, S, lo, lo, Ho, Wo)
+    old = T.gemm_tn(dz.to(D), col).view(Cout, K, K, 4)[..., :3].reshape(Cout, K * K * 3)
+    assert float((dw - old).abs().max()) <= 2e-5 * scale + 1e-5
+    dw2 = T.conv_wgrad_gather(dz.to(D), x4.to(D), B, H, W, 4, 3, K, K, S, lo, lo, Ho, Wo)
+    assert torch.equal(dw, dw2)                                                # fixed summation order
+
+
+def test_stem_weight_gradient_limits():
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd.ops import IcapError
+    with pytest.raises(IcapError):                                             # 40 output channels: more than one MFMA block
+        T.conv_wgrad_gather(rnd(2 * 4 * 4, 40, seed=1).to(D), rnd(2, 8, 8, 4, seed=2).to(D), 2, 8, 8, 4, 3, 3, 3, 2, 0, 0, 4, 4)
+    with pytest.raises(IcapError):                                             # 5 x 5 x 3 = 75 columns
+        T.conv_wgrad_gather(rnd(2 * 4 * 4, 8, seed=1).to(D), rnd(2, 8, 8, 4, seed=2).to(D), 2, 8, 8, 4, 3, 5, 5, 2, 1, 1, 4, 4)
+
+
 def _cnn():
     from image_captioning_amd.backbones import get_cnn_model
     from image_captioning_amd.synthetic import seeded_state_dict

@@ -1490,7 +1490,7 @@ int mha_bwd_f32(const float* q, const float* k, const float* v, const float* dO,
 // dtable[idx[p]][:] += dy[p][:] for p in order.  Workgroup g owns the table rows with row % EMB_GROUPS == g, so
 // every row is updated by one workgroup in position order: deterministic without atomics.  A workgroup looks at 1024
 // positions at a time, compacts the ones it owns into an LDS list (wave ballots keep them in position order) and then
-// applies them one after the other, each thread adding its own columns.  dtable must be zeroed (or hold the value to
+// applies them in that order, each thread adding its own columns (runs of one table row summed in a register first).  dtable must be zeroed (or hold the value to
 // accumulate onto) before the call.
 constexpr int EMB_GROUPS = 256;      // power of two
 constexpr int EMB_THREADS = 1024;
@@ -1522,10 +1522,33 @@ __global__ __launch_bounds__(EMB_THREADS) void embedding_bwd_kernel(const long l
             list_t[o] = (int)t;
         }
         __syncthreads();
-        for (int k = 0; k < total; ++k) {
-            const float* src = dy + (size_t)list_p[k] * ldd;
-            float* dst = dtable + (size_t)list_t[k] * E;
-            for (int e = tid; e < E; e += EMB_THREADS) dst[e] += src[e];
+        // a thread owns columns tid, tid + 1024, ...; consecutive list entries for the same table row (the padding token at
+        // the late time steps comes in long runs) are summed in a register and written once - entry by entry the loop is a
+        // chain of read-modify-write round trips through memory.  Four gradient rows are loaded ahead of their use.
+        for (int e = tid; e < E; e += EMB_THREADS) {
+            int cur = -1;
+            float acc = 0.f;
+            for (int k0 = 0; k0 < total; k0 += 4) {
+                float v[4];
+                int tr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = min(k0 + u, total - 1);
+                    tr[u] = list_t[k];
+                    v[u] = dy[(size_t)list_p[k] * ldd + e];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u >= total) break;
+                    if (tr[u] != cur) {
+                        if (cur >= 0) dtable[(size_t)cur * E + e] += acc;
+                        cur = tr[u];
+                        acc = 0.f;
+                    }
+                    acc += v[u];
+                }
+            }
+            if (cur >= 0) dtable[(size_t)cur * E + e] += acc;
         }
         __syncthreads();
     }

@@ -134,7 +134,8 @@ WORK = {"linear_f32x3": linear_x3_work, "linear_bf16": lambda s: linear_bf16_wor
         "bn_steps_bwd": lambda s: (12.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * 5),
         # (B, H, W, C, Cv, K, S, Ho, Wo, Cout): dz and the image read once
         "conv_wgrad_gather": lambda s: (2.0 * s[0] * s[7] * s[8] * s[9] * s[5] * s[5] * s[4], 4.0 * s[0] * (s[7] * s[8] * s[9] + s[1] * s[2] * s[3])),
-        "act_pool": lambda s: (3.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * 2),
+        "act_pool": lambda s: (3.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * (2 if (len(s) < 4 or s[3]) else 1)),
+        "act_gate": lambda s: (4.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * 2),
         "chan_affine": lambda s: (2.0 * s[0] * s[1] * s[2], 4.0 * s[0] * s[1] * s[2] * (2 if s[3] else 1)),
         "se_train_fwd": lambda s: (4.0 * s[0] * s[1] * s[2], 4.0 * (3 * s[0] * s[1] + 2 * s[1] * s[2])),
         "se_train_bwd": lambda s: (8.0 * s[0] * s[1] * s[2], 4.0 * (5 * s[0] * s[1] + 4 * s[1] * s[2])),

@@ -85,17 +85,21 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
     Ho, Wo = z1.shape[1], z1.shape[2]
     HW = Ho * Wo
     z1 = z1.view(B * HW, mid)
-    # BatchNorm + swish of the depthwise result, with the squeeze-excite pooling taken by the same pass
+    # BatchNorm + swish of the depthwise result: a first pass over z1 takes the squeeze-excite pooling of the activation
+    # without writing it, a second writes the GATED activation; the ungated one never exists in memory (the backward pass
+    # recomputes it from z1 where it needs it)
     bn1 = blk._bn1
-    a1, bn1_saved, pooled = T.batchnorm_train(z1, bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, bn1.eps,
-                                              bn1.momentum if bn1.momentum is not None else 0.1, act=ACT_SWISH, parts=st1, pool=(B, HW))
+    _, bn1_saved, pooled = T.batchnorm_train(z1, bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, bn1.eps,
+                                             bn1.momentum if bn1.momentum is not None else 0.1, act=ACT_SWISH, parts=st1, pool=(B, HW),
+                                             pool_only=True)
     tape.counters.append(bn1.num_batches_tracked)
+    s1, b1 = bn1_saved[2], bn1_saved[3]
     # squeeze-excite
     sq = blk._se_reduce.weight.shape[0]
     wr, br = _w2d(blk._se_reduce), blk._se_reduce.bias.detach().float().contiguous()
     we, be = _w2d(blk._se_expand), blk._se_expand.bias.detach().float().contiguous()
     r_pre, e, gate = T.se_train_fwd(pooled, wr, br, we, be)          # reduce FC + swish + expand FC + sigmoid in one launch
-    a2 = T.chan_affine(a1, gate, None, 0.0, B, HW, mid)
+    a2 = T.act_gate(z1, s1, b1, ACT_SWISH, gate, B, HW)
     z2, st2, proj_bwd = _conv1x1(tape, a2, blk._project_conv)
     y, bn2_bwd = _bn_act(tape, z2, blk._bn2, ACT_NONE, st2)
     skip = stride == 1 and cin == cout
@@ -116,7 +120,7 @@ def _mbconv(tape, blk, x, B, H, W, idx, masks):
         dyb = T.mul_mask(dy, dc_mask, group=HW * cout) if dc_mask is not None else dy
         dz2 = bn2_bwd(dyb)
         da2 = proj_bwd(dz2)
-        dgate = T.image_dot(da2, a1, B, HW, mid)
+        dgate = T.image_dot_act(da2, z1, s1, b1, ACT_SWISH, B, HW, mid)
         dpooled, dwe, dbe, dwr, dbr = T.se_train_bwd(dgate, e, r_pre, pooled, wr, we)
         tape.grad(blk._se_expand.weight, dwe)
         tape.grad(blk._se_expand.bias, dbe)

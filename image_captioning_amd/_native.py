@@ -150,6 +150,8 @@ SIGNATURES = {
     "icap_image_dot_ws_floats": (_ll, [_i, _i, _i]),
     "icap_bn_steps_fwd_f32": (_i, [_p, _p, _p, _f, _f, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "icap_bn_steps_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "icap_act_gate_f32": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _p, _p]),
+    "icap_image_dot_act_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p]),
     "icap_act_pool_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
     "icap_act_pool_ws_floats": (_ll, [_i, _i, _i]),
     "icap_bn_act_bwd_se_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),

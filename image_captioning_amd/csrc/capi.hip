@@ -142,6 +142,8 @@ int bn_steps_fwd_f32(const float*, const float*, const float*, float, float, int
 int bn_steps_bwd_f32(const float*, const float*, const float*, const float*, const float*, int, int, int, float*, float*, float*,
                      hipStream_t);
 long long act_pool_ws_floats(int, int, int);
+int act_gate_f32(const float*, const float*, const float*, int, const float*, int, int, int, float*, hipStream_t);
+int image_dot_act_f32(const float*, const float*, const float*, const float*, int, int, int, int, float, float*, float*, hipStream_t);
 int bn_act_bwd_se_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                       float, int, int, int, int, float*, float*, float*, float*, hipStream_t);
 
@@ -812,6 +814,16 @@ int icap_act_pool_f32(const float* x, const float* s, const float* b, int act, i
 }
 
 long long icap_act_pool_ws_floats(int B, int HW, int C) { return act_pool_ws_floats(B, HW, C); }
+
+int icap_act_gate_f32(const float* x, const float* s, const float* b, int act, const float* g, int B, int HW, int C, float* y,
+                      void* stream) {
+    return act_gate_f32(x, s, b, act, g, B, HW, C, y, (hipStream_t)stream);
+}
+
+int icap_image_dot_act_f32(const float* x, const float* y, const float* s2, const float* b2, int act, int B, int HW, int C, float scale,
+                           float* out, float* ws, void* stream) {
+    return image_dot_act_f32(x, y, s2, b2, act, B, HW, C, scale, out, ws, (hipStream_t)stream);
+}
 
 int icap_bn_act_bwd_se_f32(const float* dy, const float* x, const float* s, const float* b, const float* mean, const float* rstd,
                            const float* gate, const float* dpool, float alpha, int HW, int act, int M, int C, float* dgamma,

@@ -38,12 +38,72 @@ int chan_affine_f32(const float* x, const float* g, const float* a, float alpha,
     return launch_status("chan_affine");
 }
 
+// y[b,p,c] = act(x[b,p,c] * s[c] + bi[c]) * g[b][c]: BatchNorm apply + activation + squeeze-excite gate in one pass, from the
+// BatchNorm's INPUT - the ungated activation is never written (the gate needs the pooled activation of the whole image
+// first, which act_pool_kernel takes without storing anything).  A thread keeps one channel quad (the grid's stride is a
+// multiple of the quads per row), so s and bi are loaded once.
+template <int ACT>
+__global__ __launch_bounds__(256) void act_gate_kernel(const float4* __restrict__ x, const float* __restrict__ s,
+                                                       const float* __restrict__ bi, int act, const float4* __restrict__ g, int HW,
+                                                       int C4, long long rows, float4* __restrict__ y) {
+    const unsigned gtid = blockIdx.x * 256u + threadIdx.x;
+    const unsigned stride = gridDim.x * 256u;                 // a multiple of C4
+    const unsigned row_step = stride / (unsigned)C4;
+    unsigned r = gtid / (unsigned)C4;
+    const unsigned c4 = gtid - r * (unsigned)C4;
+    const float4 sv = *reinterpret_cast<const float4*>(s + (c4 << 2)), bv = *reinterpret_cast<const float4*>(bi + (c4 << 2));
+    const int a_ = ACT >= 0 ? ACT : act;
+    constexpr int RU = 4;
+    for (; r < (unsigned)rows; r += row_step * RU) {
+        float4 xv[RU], gv[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const unsigned rr = min(r + u * row_step, (unsigned)rows - 1u);
+            xv[u] = x[(size_t)rr * C4 + c4];
+            gv[u] = g[(size_t)(rr / (unsigned)HW) * C4 + c4];
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const unsigned rr = r + u * row_step;
+            if (rr >= (unsigned)rows) break;
+            y[(size_t)rr * C4 + c4] = make_float4(act_apply(fmaf(xv[u].x, sv.x, bv.x), a_) * gv[u].x, act_apply(fmaf(xv[u].y, sv.y, bv.y), a_) * gv[u].y,
+                                                  act_apply(fmaf(xv[u].z, sv.z, bv.z), a_) * gv[u].z, act_apply(fmaf(xv[u].w, sv.w, bv.w), a_) * gv[u].w);
+        }
+    }
+}
+
+int act_gate_f32(const float* x, const float* s, const float* b, int act, const float* g, int B, int HW, int C, float* y, hipStream_t st) {
+    if (!x || !s || !b || !g || !y || B <= 0 || HW <= 0 || C <= 0) { set_error("act_gate: bad arguments"); return ICAP_ERR_ARG; }
+    const long long rows = (long long)B * HW;
+    if (C % 4 || rows * (C / 4) >= (1LL << 31) || !aligned16(x) || !aligned16(y) || !aligned16(s) || !aligned16(b) || !aligned16(g)) {
+        set_error("act_gate: C %% 4 == 0, fewer than 2^31 channel quads and 16-byte aligned operands required");
+        return ICAP_ERR_ALIGN;
+    }
+    const int C4 = C / 4;
+    int gcd = C4, t256 = 256;
+    while (t256) { const int t = gcd % t256; gcd = t256; t256 = t; }
+    const long long mult = C4 / gcd;
+    long long vb = (rows * C4 + 256LL * 16 - 1) / (256LL * 16);
+    if (vb > 16384) vb = 16384;
+    vb = (vb + mult - 1) / mult * mult;
+    if (act == ACT_SWISH)
+        hipLaunchKernelGGL(act_gate_kernel<ACT_SWISH>, dim3((unsigned)vb), dim3(256), 0, st, reinterpret_cast<const float4*>(x), s, b, act,
+                           reinterpret_cast<const float4*>(g), HW, C4, rows, reinterpret_cast<float4*>(y));
+    else
+        hipLaunchKernelGGL(act_gate_kernel<-1>, dim3((unsigned)vb), dim3(256), 0, st, reinterpret_cast<const float4*>(x), s, b, act,
+                           reinterpret_cast<const float4*>(g), HW, C4, rows, reinterpret_cast<float4*>(y));
+    return launch_status("act_gate");
+}
+
 // out[b][c] = scale * sum_p x[b,p,c] * y[b,p,c]  (y == null: sum of x).  TX threads span 4*TX adjacent channels
 // (one float4 each), 256/TX threads share the rows of one chunk of one image; chunk partials go to
 // part[b][chunk][C] and image_dot_finish_kernel adds them in order.
-template <int TX>
+// With s2 != null the second operand is act(y * s2[c] + b2[c]) - an activation recomputed from its BatchNorm input instead
+// of read from a stored copy (ACT2 fixes the activation at compile time).
+template <int TX, int ACT2 = ACT_NONE>
 __global__ __launch_bounds__(256) void image_dot_kernel(const float* __restrict__ x, const float* __restrict__ y, int HW, int C,
-                                                        int rows_per_chunk, float* __restrict__ part) {
+                                                        int rows_per_chunk, float* __restrict__ part,
+                                                        const float* __restrict__ s2 = nullptr, const float* __restrict__ b2 = nullptr) {
     constexpr int TY = 256 / TX;
     __shared__ float4 red[TY][TX];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -53,10 +113,14 @@ __global__ __launch_bounds__(256) void image_dot_kernel(const float* __restrict_
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C) {
         const size_t base = (size_t)b * HW * C + c;
+        float4 sv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s2) { sv = *reinterpret_cast<const float4*>(s2 + c); bv = *reinterpret_cast<const float4*>(b2 + c); }
         for (int p = p_lo + ty; p < p_hi; p += TY) {
             const float4 xv = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
             if (y) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + base + (size_t)p * C);
+                float4 yv = *reinterpret_cast<const float4*>(y + base + (size_t)p * C);
+                if (s2) yv = make_float4(act_c<ACT2>(fmaf(yv.x, sv.x, bv.x)), act_c<ACT2>(fmaf(yv.y, sv.y, bv.y)),
+                                         act_c<ACT2>(fmaf(yv.z, sv.z, bv.z)), act_c<ACT2>(fmaf(yv.w, sv.w, bv.w)));
                 s.x = fmaf(xv.x, yv.x, s.x); s.y = fmaf(xv.y, yv.y, s.y); s.z = fmaf(xv.z, yv.z, s.z); s.w = fmaf(xv.w, yv.w, s.w);
             } else {
                 s.x += xv.x; s.y += xv.y; s.z += xv.z; s.w += xv.w;
@@ -105,24 +169,42 @@ long long image_dot_ws_floats(int B, int HW, int C) {
     return (long long)B * ((HW + rows - 1) / rows) * C;
 }
 
-int image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, float* ws, hipStream_t st) {
-    if (!x || !out || !ws || B <= 0 || HW <= 0 || C <= 0) { set_error("image_dot: bad arguments"); return ICAP_ERR_ARG; }
-    if (C % 4 || !aligned16(x) || (y && !aligned16(y)) || !aligned16(ws)) { set_error("image_dot: C %% 4 and 16-byte alignment required"); return ICAP_ERR_ALIGN; }
+template <int ACT2>
+static void image_dot_launch(int tx, dim3 grid, hipStream_t st, const float* x, const float* y, int HW, int C, int rows, float* ws,
+                             const float* s2, const float* b2) {
+    switch (tx) {
+        case 8: hipLaunchKernelGGL((image_dot_kernel<8, ACT2>), grid, dim3(256), 0, st, x, y, HW, C, rows, ws, s2, b2); break;
+        case 16: hipLaunchKernelGGL((image_dot_kernel<16, ACT2>), grid, dim3(256), 0, st, x, y, HW, C, rows, ws, s2, b2); break;
+        case 32: hipLaunchKernelGGL((image_dot_kernel<32, ACT2>), grid, dim3(256), 0, st, x, y, HW, C, rows, ws, s2, b2); break;
+        default: hipLaunchKernelGGL((image_dot_kernel<64, ACT2>), grid, dim3(256), 0, st, x, y, HW, C, rows, ws, s2, b2); break;
+    }
+}
+
+// s2, b2 (both or neither): the second operand is act(y * s2[c] + b2[c]); act must be ACT_NONE or ACT_SWISH then
+int image_dot_act_f32(const float* x, const float* y, const float* s2, const float* b2, int act, int B, int HW, int C, float scale,
+                      float* out, float* ws, hipStream_t st) {
+    if (!x || !out || !ws || B <= 0 || HW <= 0 || C <= 0 || (!s2) != (!b2) || (s2 && !y)) { set_error("image_dot: bad arguments"); return ICAP_ERR_ARG; }
+    if (s2 && act != ACT_NONE && act != ACT_SWISH) { set_error("image_dot: activation %d on the second operand is not built", act); return ICAP_ERR_ARG; }
+    if (C % 4 || !aligned16(x) || (y && !aligned16(y)) || !aligned16(ws) || (s2 && (!aligned16(s2) || !aligned16(b2)))) {
+        set_error("image_dot: C %% 4 and 16-byte alignment required");
+        return ICAP_ERR_ALIGN;
+    }
     const int rows = image_dot_rows(B, HW, C), nchunks = (HW + rows - 1) / rows, c4 = C / 4;
     const int tx = c4 <= 8 ? 8 : (c4 <= 16 ? 16 : (c4 <= 32 ? 32 : 64));
     const dim3 grid((c4 + tx - 1) / tx, nchunks, B);
-    switch (tx) {
-        case 8: hipLaunchKernelGGL(image_dot_kernel<8>, grid, dim3(256), 0, st, x, y, HW, C, rows, ws); break;
-        case 16: hipLaunchKernelGGL(image_dot_kernel<16>, grid, dim3(256), 0, st, x, y, HW, C, rows, ws); break;
-        case 32: hipLaunchKernelGGL(image_dot_kernel<32>, grid, dim3(256), 0, st, x, y, HW, C, rows, ws); break;
-        default: hipLaunchKernelGGL(image_dot_kernel<64>, grid, dim3(256), 0, st, x, y, HW, C, rows, ws); break;
-    }
+    if (s2 && act == ACT_SWISH) image_dot_launch<ACT_SWISH>(tx, grid, st, x, y, HW, C, rows, ws, s2, b2);
+    else image_dot_launch<ACT_NONE>(tx, grid, st, x, y, HW, C, rows, ws, s2, b2);
     hipLaunchKernelGGL(image_dot_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, ws, nchunks, C, B * C, scale, out);
     return launch_status("image_dot");
 }
 
+int image_dot_f32(const float* x, const float* y, int B, int HW, int C, float scale, float* out, float* ws, hipStream_t st) {
+    return image_dot_act_f32(x, y, nullptr, nullptr, ACT_NONE, B, HW, C, scale, out, ws, st);
+}
+
 // y[b,p,c] = act(x[b,p,c] * s[c] + bi[c]) and out[b][c] = scale * sum_p y[b,p,c] in the same pass: the BatchNorm apply in
-// front of a squeeze-excite block and the block's global pooling.  Same thread layout and chunk partials as
+// front of a squeeze-excite block and the block's global pooling.  y == null: only the pooled sums (act_gate_kernel writes
+// the gated activation from x afterwards).  Same thread layout and chunk partials as
 // image_dot_kernel; four row positions in flight per thread.
 template <int TX, int ACT>      // ACT >= 0: the activation fixed at compile time; < 0: the `act` argument
 __global__ __launch_bounds__(256) void act_pool_kernel(const float* __restrict__ x, const float* __restrict__ s,
@@ -148,7 +230,7 @@ __global__ __launch_bounds__(256) void act_pool_kernel(const float* __restrict__
                 if (p + u * TY >= p_hi) break;
                 const float4 v = make_float4(act_apply(fmaf(xv[u].x, sv.x, bv.x), a_), act_apply(fmaf(xv[u].y, sv.y, bv.y), a_),
                                              act_apply(fmaf(xv[u].z, sv.z, bv.z), a_), act_apply(fmaf(xv[u].w, sv.w, bv.w), a_));
-                *reinterpret_cast<float4*>(y + base + (size_t)(p + u * TY) * C) = v;
+                if (y) *reinterpret_cast<float4*>(y + base + (size_t)(p + u * TY) * C) = v;
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
         }
@@ -200,8 +282,8 @@ long long act_pool_ws_floats(int B, int HW, int C) {
 
 int act_pool_f32(const float* x, const float* s, const float* b, int act, int B, int HW, int C, float scale, float* y, float* out,
                  float* ws, hipStream_t st) {
-    if (!x || !s || !b || !y || !out || !ws || B <= 0 || HW <= 0 || C <= 0) { set_error("act_pool: bad arguments"); return ICAP_ERR_ARG; }
-    if (C % 4 || !aligned16(x) || !aligned16(y) || !aligned16(s) || !aligned16(b) || !aligned16(ws)) {
+    if (!x || !s || !b || !out || !ws || B <= 0 || HW <= 0 || C <= 0) { set_error("act_pool: bad arguments"); return ICAP_ERR_ARG; }
+    if (C % 4 || !aligned16(x) || (y && !aligned16(y)) || !aligned16(s) || !aligned16(b) || !aligned16(ws)) {
         set_error("act_pool: C %% 4 and 16-byte alignment required");
         return ICAP_ERR_ALIGN;
     }

@@ -147,13 +147,15 @@ def col_sum(a, out=None, accumulate=False, scale=1.0):
     return col_reduce(COL_SUM, a, out1=out, accumulate=accumulate, scale=scale)[0]
 
 
-def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NONE, res=None, out=None, parts=None, pool=None):
+def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NONE, res=None, out=None, parts=None, pool=None,
+                    pool_only=False):
     """BatchNorm over the rows of x [M, C] with batch statistics (+ activation, + residual); updates the running
     statistics in place.  Returns (y, saved) with saved = (mean, rstd, s, b) for the backward pass.
     parts (ops.StatParts): the column statistics the kernel that produced x left behind - the pass over x that would
     otherwise take them is skipped.
     pool = (B, HW): the rows are B images of HW positions and the per-image channel means of y are wanted too (taken by
-    the pass that writes y); returns (y, saved, pooled [B, C])."""
+    the pass that writes y); returns (y, saved, pooled [B, C]).  pool_only: y is not written at all (None is returned
+    for it) - for a consumer that recomputes the activation from x with saved's scale and bias (act_gate)."""
     _ckr(x, "x")
     M, C = x.shape
     dev = x.device
@@ -165,7 +167,7 @@ def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NO
                                                  float(eps), float(momentum), mean.data_ptr(), rstd.data_ptr(), s.data_ptr(), b.data_ptr(),
                                                  _p(run_mean), _p(run_var), ws.data_ptr(), _stream()), "bn_stats_from_parts")
         if pool is not None:
-            y, pooled = act_pool(x, s, b, act, pool[0], pool[1])
+            y, pooled = act_pool(x, s, b, act, pool[0], pool[1], write=not pool_only)
             return y, (mean, rstd, s, b), pooled
         y = scale_bias_act(x, s, b, act=act, res=res, out=out)
         return y, (mean, rstd, s, b)
@@ -180,7 +182,7 @@ def batchnorm_train(x, gamma, beta, run_mean, run_var, eps, momentum, act=ACT_NO
                                         ws.data_ptr(), _stream()), "bn_train_stats")
     span.done()
     if pool is not None:
-        y, pooled = act_pool(x, s, b, act, pool[0], pool[1])
+        y, pooled = act_pool(x, s, b, act, pool[0], pool[1], write=not pool_only)
         return y, (mean, rstd, s, b), pooled
     y = scale_bias_act(x, s, b, act=act, res=res, out=out)
     return y, (mean, rstd, s, b)
@@ -232,21 +234,48 @@ def batchnorm_steps_bwd(dy, x, saved, B, Tn):
     return dx, dg, db
 
 
-def act_pool(x, s, b, act, B, HW):
-    """y = act(x * s + b) over x [B*HW, C] and the per-image channel means of y, in one pass -> (y, pooled [B, C])."""
+def act_pool(x, s, b, act, B, HW, write=True):
+    """y = act(x * s + b) over x [B*HW, C] and the per-image channel means of y, in one pass -> (y, pooled [B, C]).
+    write=False: only the means (y is returned as None)."""
     _ckr(x, "x")
     M, C = x.shape
     if M != B * HW or not x.is_contiguous():
         raise N.IcapError("act_pool: x must be a dense [B*HW, C] matrix")
     lib = N.load()
-    y = torch.empty(M, C, device=x.device, dtype=torch.float32)
+    y = torch.empty(M, C, device=x.device, dtype=torch.float32) if write else None
     pooled = torch.empty(B, C, device=x.device, dtype=torch.float32)
     ws = _ws(lib.icap_act_pool_ws_floats(B, HW, C), x.device)
-    span = _Span("act_pool", (B, HW, C))
-    N.check(lib.icap_act_pool_f32(x.data_ptr(), s.data_ptr(), b.data_ptr(), act, B, HW, C, 1.0 / HW, y.data_ptr(), pooled.data_ptr(),
+    span = _Span("act_pool", (B, HW, C, write))
+    N.check(lib.icap_act_pool_f32(x.data_ptr(), s.data_ptr(), b.data_ptr(), act, B, HW, C, 1.0 / HW, _p(y), pooled.data_ptr(),
                                   ws.data_ptr(), _stream()), "act_pool")
     span.done()
     return y, pooled
+
+
+def act_gate(x, s, b, act, g, B, HW):
+    """act(x * s + b) * g[image] over x [B*HW, C] with g [B, C]: BatchNorm apply, activation and squeeze-excite gate in one pass."""
+    _ckr(x, "x")
+    M, C = x.shape
+    if M != B * HW or not x.is_contiguous() or tuple(g.shape) != (B, C):
+        raise N.IcapError("act_gate: x must be a dense [B*HW, C] matrix and g [B, C]")
+    y = torch.empty(M, C, device=x.device, dtype=torch.float32)
+    span = _Span("act_gate", (B, HW, C))
+    N.check(N.load().icap_act_gate_f32(x.data_ptr(), s.data_ptr(), b.data_ptr(), act, g.data_ptr(), B, HW, C, y.data_ptr(), _stream()),
+            "act_gate")
+    span.done()
+    return y
+
+
+def image_dot_act(x, z, s, b, act, B, HW, C, scale=1.0):
+    """[B, C] per-image sums of x * act(z * s + b): image_dot against an activation recomputed from its BatchNorm input."""
+    lib = N.load()
+    out = torch.empty(B, C, device=x.device, dtype=torch.float32)
+    ws = _ws(lib.icap_image_dot_ws_floats(B, HW, C), x.device)
+    span = _Span("image_dot", (B, HW, C, True))
+    N.check(lib.icap_image_dot_act_f32(x.data_ptr(), z.data_ptr(), s.data_ptr(), b.data_ptr(), act, B, HW, C, float(scale), out.data_ptr(),
+                                       ws.data_ptr(), _stream()), "image_dot_act")
+    span.done()
+    return out
 
 
 def batchnorm_act_bwd_se(dy, x, saved, gate, dpool, alpha, HW, act=ACT_NONE):

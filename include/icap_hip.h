@@ -611,11 +611,21 @@ int icap_image_dot_f32(const float* x, const float* y, int B, int HW, int C, flo
 long long icap_image_dot_ws_floats(int B, int HW, int C);
 /* The BatchNorm apply in front of a squeeze-excite block together with the block's pooling (efficientnet_pytorch MBConvBlock:
  * _bn1 -> swish -> adaptive_avg_pool2d, train mode under transformer_word_level_bahdnau.py:12-25), one pass instead of two:
- * y[b,p,c] = act(x[b,p,c] * s[c] + b[c]), pooled[b][c] = scale * sum_p y[b,p,c].  C % 4 == 0, 16-byte aligned operands
+ * y[b,p,c] = act(x[b,p,c] * s[c] + b[c]), pooled[b][c] = scale * sum_p y[b,p,c].  y may be NULL (only the pooled means:
+ * icap_act_gate_f32 then writes the gated activation straight from x).  C % 4 == 0, 16-byte aligned operands
  * (error 2 otherwise).  ws: icap_act_pool_ws_floats(B, HW, C) floats.  The sums are taken in a fixed order. */
 int icap_act_pool_f32(const float* x, const float* s, const float* b, int act, int B, int HW, int C, float scale, float* y,
                       float* pooled, float* ws, void* stream);
 long long icap_act_pool_ws_floats(int B, int HW, int C);
+/* y[b,p,c] = act(x[b,p,c] * s[c] + b[c]) * g[b][c]: BatchNorm apply + activation + squeeze-excite gate from the BatchNorm's
+ * input (same lines: _bn1 -> swish -> ... -> sigmoid gate -> multiply), so that the ungated activation is never stored.
+ * icap_image_dot_act_f32 is icap_image_dot_f32 with its second operand recomputed the same way, act(y * s2[c] + b2[c])
+ * (act 0 or swish) - the gate's gradient sum_p dy * swish(bn(z)) without the stored activation.  C % 4 == 0, 16-byte
+ * aligned operands (error 2 otherwise). */
+int icap_act_gate_f32(const float* x, const float* s, const float* b, int act, const float* g, int B, int HW, int C, float* y,
+                      void* stream);
+int icap_image_dot_act_f32(const float* x, const float* y, const float* s2, const float* b2, int act, int B, int HW, int C,
+                           float scale, float* out, float* ws, void* stream);
 /* Gradient of y = act(BatchNorm_train(x)) when the arriving gradient still has to pass the squeeze-excite gate (same lines,
  * backward): dy_eff[b,p,c] = dy[b,p,c] * gate[b][c] + dpool[b][c] * alpha is formed on the fly by both passes (the two column
  * sums dgamma / dbeta [C], then dx) and never written out.  x, dy, dx dense [B*HW][C]; gate, dpool [B][C]; s, b, mean, rstd:

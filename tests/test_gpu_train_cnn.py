@@ -63,6 +63,28 @@ def test_act_pool_matches_separate_passes(B, HW, C):
         assert torch.equal(pooled, pooled2) and torch.equal(y, y2)             # fixed summation order
 
 
+@pytest.mark.parametrize("B,HW,C", [(3, 49, 32), (5, 196, 144), (2, 3136, 24), (4, 50, 1152), (7, 33, 40)])
+def test_gated_activation_and_its_gate_gradient_without_the_stored_activation(B, HW, C):
+    """act_pool(write=False) + act_gate write swish(bn(z)) * gate straight from z, and image_dot_act takes the gate's gradient
+    from z: the same numbers as the forms that go through a stored activation."""
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd.ops import ACT_SWISH
+    z, s, b = rnd(B * HW, C, seed=11), rnd(C, seed=12), rnd(C, seed=13)
+    gate, dy = torch.sigmoid(rnd(B, C, seed=14)), rnd(B * HW, C, seed=15)
+    zg, sg, bg, gg = z.to(D), s.to(D), b.to(D), gate.to(D)
+    a1, pooled = T.act_pool(zg, sg, bg, ACT_SWISH, B, HW)
+    none, pooled2 = T.act_pool(zg, sg, bg, ACT_SWISH, B, HW, write=False)
+    assert none is None and torch.equal(pooled, pooled2)
+    a2 = T.act_gate(zg, sg, bg, ACT_SWISH, gg, B, HW)
+    want = F.silu(z.double() * s.double() + b.double()).view(B, HW, C) * gate.double()[:, None, :]
+    torch.testing.assert_close(a2.cpu().double().view(B, HW, C), want, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a2, T.chan_affine(a1, gg, None, 0.0, B, HW, C), rtol=1e-6, atol=1e-7)
+    dgate = T.image_dot_act(dy.to(D), zg, sg, bg, ACT_SWISH, B, HW, C)
+    torch.testing.assert_close(dgate, T.image_dot(dy.to(D), a1, B, HW, C), rtol=1e-5, atol=1e-5)
+    ref = (dy.double() * F.silu(z.double() * s.double() + b.double())).view(B, HW, C).sum(1)
+    torch.testing.assert_close(dgate.cpu().double(), ref, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("B,HW,C", [(3, 49, 32), (5, 196, 144), (2, 3136, 24), (4, 50, 1152), (9, 33, 40)])
 def test_gated_batchnorm_gradient_matches_the_two_step_form(B, HW, C):
     """The squeeze-excite gate applied inside the BatchNorm-gradient passes against chan_affine followed by the plain

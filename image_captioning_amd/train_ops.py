@@ -36,6 +36,8 @@ def accumulate_into_grads(params, grads):
     multi-tensor add instead of autograd's one small add per parameter (213 of them for the EfficientNet) - and then runs
     the parameters' post-accumulate hooks, as autograd would have.  Returns the gradients still to be handed to autograd:
     None where the sum was taken here, grads[i] elsewhere (no buffer yet, other shape or dtype)."""
+    if not hasattr(torch.Tensor, "_post_accumulate_grad_hooks"):
+        return tuple(grads)         # no way to run the hooks ourselves on this torch: leave every gradient to autograd
     dst, src, idx = [], [], []
     for i, (p, g) in enumerate(zip(params, grads)):
         if g is None or p.grad is None or p.grad.shape != g.shape or p.grad.dtype != g.dtype or p.grad.device != g.device:

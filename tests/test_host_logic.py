@@ -177,3 +177,26 @@ def test_stat_parts_descriptor_and_cpu_rejection():
                      (ops.linear_x3dl, (torch.zeros(3, 4, 32, dtype=torch.bfloat16), torch.zeros(3, 8, 32, dtype=torch.bfloat16)))):
         with pytest.raises(ops.IcapError):
             fn(*args)
+
+
+def test_accumulate_into_grads_adds_in_one_call_and_runs_the_hooks():
+    """The multi-tensor gradient add used by the CNN's backward: sums land in the existing .grad buffers, the parameters'
+    post-accumulate hooks run (the optimizer's `touched` flags and the data-parallel buckets hang on them), and
+    parameters without a buffer are handed back for autograd to deal with."""
+    import torch
+    from image_captioning_amd import train_ops as T
+    from image_captioning_amd.training import FlatParameters
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
+    flat = FlatParameters(ps[:2])                     # the third parameter has no gradient buffer
+    fired = []
+    ps[1].register_post_accumulate_grad_hook(lambda p: fired.append(p))
+    flat.zero_grad()
+    g = [torch.ones(3, 4), None, torch.full((2, 2), 2.0)]
+    left = T.accumulate_into_grads(ps, g)
+    assert left[0] is None and left[1] is None and left[2] is g[2]
+    assert flat.touched == [True, False] and fired == []
+    left = T.accumulate_into_grads(ps, [torch.ones(3, 4), torch.full((5,), 3.0), None])
+    assert left == (None, None, None)
+    assert flat.touched == [True, True] and len(fired) == 1 and fired[0] is ps[1]
+    assert torch.equal(ps[0].grad, torch.full((3, 4), 2.0)) and torch.equal(ps[1].grad, torch.full((5,), 3.0))
+    assert ps[0].grad.data_ptr() == flat.flat_g.data_ptr()          # still the flat buffer's view

@@ -115,15 +115,29 @@ __global__ __launch_bounds__(256) void image_dot_kernel(const float* __restrict_
         const size_t base = (size_t)b * HW * C + c;
         float4 sv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s2) { sv = *reinterpret_cast<const float4*>(s2 + c); bv = *reinterpret_cast<const float4*>(b2 + c); }
-        for (int p = p_lo + ty; p < p_hi; p += TY) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
-            if (y) {
-                float4 yv = *reinterpret_cast<const float4*>(y + base + (size_t)p * C);
-                if (s2) yv = make_float4(act_c<ACT2>(fmaf(yv.x, sv.x, bv.x)), act_c<ACT2>(fmaf(yv.y, sv.y, bv.y)),
-                                         act_c<ACT2>(fmaf(yv.z, sv.z, bv.z)), act_c<ACT2>(fmaf(yv.w, sv.w, bv.w)));
-                s.x = fmaf(xv.x, yv.x, s.x); s.y = fmaf(xv.y, yv.y, s.y); s.z = fmaf(xv.z, yv.z, s.z); s.w = fmaf(xv.w, yv.w, s.w);
-            } else {
-                s.x += xv.x; s.y += xv.y; s.z += xv.z; s.w += xv.w;
+        // four row positions per iteration, their loads issued before the first is used (rows beyond the chunk read a
+        // clamped address and are skipped)
+        constexpr int RU = 4;
+        for (int p = p_lo + ty; p < p_hi; p += RU * TY) {
+            float4 xq[RU], yq[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const size_t o = base + (size_t)min(p + u * TY, p_hi - 1) * C;
+                xq[u] = *reinterpret_cast<const float4*>(x + o);
+                if (y) yq[u] = *reinterpret_cast<const float4*>(y + o);
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                if (p + u * TY >= p_hi) break;
+                const float4 xv = xq[u];
+                if (y) {
+                    float4 yv = yq[u];
+                    if (s2) yv = make_float4(act_c<ACT2>(fmaf(yv.x, sv.x, bv.x)), act_c<ACT2>(fmaf(yv.y, sv.y, bv.y)),
+                                             act_c<ACT2>(fmaf(yv.z, sv.z, bv.z)), act_c<ACT2>(fmaf(yv.w, sv.w, bv.w)));
+                    s.x = fmaf(xv.x, yv.x, s.x); s.y = fmaf(xv.y, yv.y, s.y); s.z = fmaf(xv.z, yv.z, s.z); s.w = fmaf(xv.w, yv.w, s.w);
+                } else {
+                    s.x += xv.x; s.y += xv.y; s.z += xv.z; s.w += xv.w;
+                }
             }
         }
     }
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(256) void image_dot_finish_kernel(const float* __re
 
 static int image_dot_rows(int B, int HW, int C) {
     const int col_blocks = (C + 255) / 256;
-    long long want = 1024 / ((long long)B * col_blocks);
+    long long want = 2048 / ((long long)B * col_blocks);
     if (want < 1) want = 1;
     long long rows = (HW + want - 1) / want;
     if (rows < 32) rows = 32;

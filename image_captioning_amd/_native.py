@@ -79,6 +79,7 @@ SIGNATURES = {
     "icap_adaptive_avgpool2d_f32": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "icap_embedding_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "icap_layernorm_f32": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _f, _f, _p]),
+    "icap_layernorm_split3_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _f, _p]),
     "icap_argmax_rows_f32": (_i, [_p, _i, _p, _i, _i, _i, _p, _p]),
     "icap_linear_bf16_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "icap_header_hash": (C.c_uint, []),

@@ -323,9 +323,9 @@ class ImageCaptioningModelBase(nn.Module):
                 # fp32-accurate products on the bf16 matrix cores for the GEMMs they speed up (ops.linear_x3_auto decides)
                 h = ops.linear_x3_auto(x, wd["fc1_w"], wd, "fc1_w3", wd["fc1_b"], act=ops.ACT_RELU)
                 f = ops.linear_x3_auto(h, wd["fc2_w"], wd, "fc2_w3", wd["fc2_b"], residual=x)
-                x2 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"])
-                # 53 column tiles would each repeat the split of x2: split it once
-                pv, pi, logits = ops.linear_f32x3_argmax(ops.split3(x2), wd["out_w3"], wd["out_b4"], want_logits=want_logits)
+                # 53 column tiles would each repeat the split of the LayerNorm's result: the LayerNorm kernel writes it split
+                x23 = ops.layernorm(f, wd["ln3_g"], wd["ln3_b"], split=True)
+                pv, pi, logits = ops.linear_f32x3_argmax(x23, wd["out_w3"], wd["out_b4"], want_logits=want_logits)
                 x = ops.next_token(pv, pi, ids, t, None if last else wd["emb"], None if last else ca,
                                    None if last else wd["ln2_g"], None if last else wd["ln2_b"])
             else:

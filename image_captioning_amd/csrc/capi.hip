@@ -77,6 +77,8 @@ int maxpool2d_f32(const float*, float*, int, int, int, int, int, int, int, int, 
 int adaptive_avgpool2d_f32(const float*, float*, int, int, int, int, int, int, hipStream_t);
 int embedding_f32(const float*, const long long*, const float*, float*, int, int, int, int, int*, hipStream_t);
 int layernorm_f32(const float*, const float*, int, const float*, const float*, float*, int, int, float, float, hipStream_t);
+int layernorm_split3_f32(const float*, const float*, int, const float*, const float*, float*, unsigned short*, int, int, float, float,
+                         hipStream_t);
 int argmax_rows_f32(const float*, int, long long*, int, int, int, float*, hipStream_t);
 int mha_core_f32(const float*, const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
 int bahdanau_attention_f32(const float*, const float*, const float*, float, const float*, float*, float*, int, int, int,
@@ -350,6 +352,11 @@ int icap_embedding_f32(const float* table, const long long* idx, const float* ad
 int icap_layernorm_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta, float* y,
                        int rows, int E, float eps, float pre_scale, void* stream) {
     return layernorm_f32(x, res, res_rows, gamma, beta, y, rows, E, eps, pre_scale, (hipStream_t)stream);
+}
+
+int icap_layernorm_split3_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta, float* y,
+                              unsigned short* y3, int rows, int E, float eps, float pre_scale, void* stream) {
+    return layernorm_split3_f32(x, res, res_rows, gamma, beta, y, y3, rows, E, eps, pre_scale, (hipStream_t)stream);
 }
 
 int icap_argmax_rows_f32(const float* logits, int ld, long long* idx, int idx_stride, int rows, int V, float* top2gap,

@@ -36,10 +36,22 @@ int embedding_f32(const float* table, const long long* idx, const float* add, fl
 // 64 * LN_MAXV elements are read once and kept in registers (mean, then centred variance, then output).
 constexpr int LN_MAXV = 16;
 
+typedef float ln_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ln_bf16x2 __attribute__((ext_vector_type(2)));
+
+// bf16 (round to nearest even) of v, as its 16 bits
+__device__ __forceinline__ unsigned short ln_bf16_bits(float v) {
+    const ln_f32x2 p = {v, 0.f};
+    return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(p, ln_bf16x2)) & 0xffffu);
+}
+
+// y3 (optional): the result also as its exact three-way bf16 split, planes [3][rows * E] (hi = bf16(v), mid = bf16(v - hi),
+// lo = bf16(v - hi - mid)) - what the split-product GEMMs take as a pre-split activation; y may then be null.
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                         int res_rows, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                        int rows, int E, float eps, float pre_scale) {
+                                                        int rows, int E, float eps, float pre_scale,
+                                                        unsigned short* __restrict__ y3) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;
@@ -70,20 +82,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int e = lane + 64 * i;
-        if (e < E) y[(size_t)r * E + e] = (v[i] - mean) * rstd * gamma[e] + beta[e];
+        if (e < E) {
+            float o = (v[i] - mean) * rstd * gamma[e] + beta[e];
+            const size_t at = (size_t)r * E + e;
+            if (y) y[at] = o;
+            if (y3) {
+                const size_t n = (size_t)rows * E;
+                const unsigned short h = ln_bf16_bits(o);
+                o -= __uint_as_float((unsigned)h << 16);
+                const unsigned short m = ln_bf16_bits(o);
+                o -= __uint_as_float((unsigned)m << 16);
+                y3[at] = h;
+                y3[n + at] = m;
+                y3[2 * n + at] = ln_bf16_bits(o);
+            }
+        }
     }
 }
 
-int layernorm_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta,
-                  float* y, int rows, int E, float eps, float pre_scale, hipStream_t st) {
-    if (!x || !gamma || !beta || !y || rows <= 0 || E <= 0 || (res && res_rows <= 0)) {
+int layernorm_split3_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta, float* y,
+                         unsigned short* y3, int rows, int E, float eps, float pre_scale, hipStream_t st) {
+    if (!x || !gamma || !beta || (!y && !y3) || rows <= 0 || E <= 0 || (res && res_rows <= 0)) {
         set_error("layernorm: bad arguments");
         return ICAP_ERR_ARG;
     }
     if (E > 64 * LN_MAXV) { set_error("layernorm: E=%d exceeds %d", E, 64 * LN_MAXV); return ICAP_ERR_LIMIT; }
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, res, res ? res_rows : 1,
-                       gamma, beta, y, rows, E, eps, pre_scale);
+                       gamma, beta, y, rows, E, eps, pre_scale, y3);
     return launch_status("layernorm");
+}
+
+int layernorm_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta,
+                  float* y, int rows, int E, float eps, float pre_scale, hipStream_t st) {
+    if (!y) { set_error("layernorm: bad arguments"); return ICAP_ERR_ARG; }
+    return layernorm_split3_f32(x, res, res_rows, gamma, beta, y, nullptr, rows, E, eps, pre_scale, st);
 }
 
 // ---------------------------------------------------------------- argmax over rows

@@ -651,13 +651,20 @@ def embedding(table, idx, add=None):
     return out, err
 
 
-def layernorm(x, gamma, beta, res=None, eps=1e-5, pre_scale=1.0):
+def layernorm(x, gamma, beta, res=None, eps=1e-5, pre_scale=1.0, split=False):
+    """split=True: returns split3(LayerNorm(...)) - the bf16 [3, rows, E] planes a split-product GEMM takes as a pre-split
+    activation - written by the LayerNorm kernel itself; the fp32 result is not stored."""
     rows, E = x.shape
     res_rows = 1
     if res is not None:
         if res.shape[-1] != E or rows % (res.numel() // E):
             raise IcapError("layernorm: residual rows must divide x rows")
         res_rows = res.numel() // E
+    if split:
+        y3 = torch.empty((3, rows, E), device=x.device, dtype=torch.bfloat16)
+        N.check(N.load().icap_layernorm_split3_f32(_ck(x, "x"), _ck(res, "res"), res_rows, _ck(gamma, "gamma"), _ck(beta, "beta"),
+                                                   None, y3.data_ptr(), rows, E, eps, pre_scale, _stream()), "layernorm_split3")
+        return y3
     y = torch.empty_like(x)
     N.check(N.load().icap_layernorm_f32(_ck(x, "x"), _ck(res, "res"), res_rows, _ck(gamma, "gamma"), _ck(beta, "beta"),
                                         _ck(y, "y"), rows, E, eps, pre_scale, _stream()), "layernorm")

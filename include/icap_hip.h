@@ -175,6 +175,11 @@ int icap_embedding_f32(const float* table, const long long* idx, const float* ad
  * transformer_word_level.py:46,48,75,77; transformer_word_level_bahdnau.py:77,88. */
 int icap_layernorm_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta,
                        float* y, int rows, int E, float eps, float pre_scale, void* stream);
+/* The same LayerNorm, its result also (y3) or only (y NULL) as the exact three-way bf16 split icap_split3_f32 would make of
+ * it, planes [3][rows*E]: the pre-split activation of icap_linear_f32x3_argmax_f32 without a pass of its own (the greedy
+ * loop's LayerNorm in front of the vocabulary projection; same reference lines). */
+int icap_layernorm_split3_f32(const float* x, const float* res, int res_rows, const float* gamma, const float* beta,
+                              float* y, unsigned short* y3, int rows, int E, float eps, float pre_scale, void* stream);
 
 /* idx[r*idx_stride] = argmax(logits[r][0..V)) (first maximum); top2gap[r] (optional)
  * = best - runner-up.  seq2seqbasic.py:81 and the greedy form of TransformerTest.py:147-157. */

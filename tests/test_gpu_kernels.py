@@ -414,3 +414,17 @@ def test_linear_f32x3_with_presplit_activations():
     assert torch.equal(pv0, pv1) and torch.equal(pi0, pi1) and torch.equal(lg0, lg1)
     with pytest.raises(ops.IcapError):
         ops.linear_f32x3(x3, w3, gate=torch.ones(M, K, device=d))
+
+
+@pytest.mark.parametrize("rows,E", [(11, 512), (1024, 512), (5, 96), (3, 1000)])
+def test_layernorm_writes_its_result_split(rows, E):
+    """ops.layernorm(split=True): the planes are bit for bit split3 of the fp32 LayerNorm result, and they add back up to it."""
+    from image_captioning_amd import ops
+    d = dev()
+    x, res, g, b = rnd(rows, E, seed=3).to(d), rnd(rows, E, seed=4).to(d), rnd(E, seed=5).to(d), rnd(E, seed=6).to(d)
+    y = ops.layernorm(x, g, b, res=res)
+    y3 = ops.layernorm(x, g, b, res=res, split=True)
+    assert y3.dtype == torch.bfloat16 and tuple(y3.shape) == (3, rows, E)
+    assert torch.equal(y3.view(torch.int16), ops.split3(y).view(torch.int16))
+    back = y3[0].double() + y3[1].double() + y3[2].double()
+    assert float((back - y.double()).abs().max()) <= 2e-7 * float(y.abs().max())

@@ -79,6 +79,7 @@ class EncoderBlockTrain(torch.autograd.Function):
         out, ln2_saved = T.layernorm_train(f_d, ln2_g.detach(), ln2_b.detach(), eps=mod.layer_norm2.eps, pre_scale=2.0)
         ctx.saved = (rows, wv, v, m_att, ln1_saved, x1, h, m_h, h_d, bn_saved, hb, m_f, ln2_saved)
         ctx.params = (in_w, out_w, ln1_g, ln2_g, w0, w4)
+        ctx.all_params = (in_w, in_b, out_w, out_b, ln1_g, ln1_b, ln2_g, ln2_b, w0, b0, bn_g, bn_b, w4, b4)
         return out
 
     @staticmethod
@@ -109,7 +110,10 @@ class EncoderBlockTrain(torch.autograd.Function):
         T.col_sum(dv, out=din_b[2 * E:])
         drows = T.gemm_nn(dv, wv)
         T.axpby(dsum, drows)                           # residual branch of LayerNorm1
-        return (drows, din_w, din_b, dout_w, dout_b, dln1_g, dln1_b, dln2_g, dln2_b, dw0, db0, dbn_g, dbn_b, dw4, db4, None, None)
+        # parameter gradients go into their buffers by one multi-tensor add (hooks included) where buffers exist
+        pg = T.accumulate_into_grads(ctx.all_params, (din_w, din_b, dout_w, dout_b, dln1_g, dln1_b, dln2_g, dln2_b, dw0, db0, dbn_g, dbn_b,
+                                                      dw4, db4))
+        return (drows,) + pg + (None, None)
 
 
 def encoder_block_train(mod, rows, masks=None):
@@ -186,6 +190,7 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         bn.num_batches_tracked += Tn
         ctx.saved = (feats, idx, emb_all, w_ih_e, w_ih_c, u, a_w, Hprev, Cs, Ws, Al, Ctx, G, hd, m_out, pre, bn_saved)
         ctx.params = (W_w, U_w, w_ih, w_hh, fc_w, emb_w)
+        ctx.all_params = (W_w, W_b, U_w, U_b, A_w, A_b, emb_w, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, bn_g, bn_b)
         ctx.dims = (B, Tn, E, H, ENC, V)
         return out
 
@@ -258,8 +263,11 @@ class BahdanauDecoderTrain(torch.autograd.Function):
         dU_b = T.col_sum(du)
         T.gemm_nn(du, U_w.detach(), out=dfeat, accumulate=True)
         demb_w = T.embedding_bwd(idx, dEmb, emb_w.shape[0])
-        return (dfeat, dW_w, dW_b, dU_w, dU_b, dA_w, dA_b, demb_w, dw_ih, dw_hh, db_g, db_g.clone(), dfc_w, dfc_b, dbn_g, dbn_b,
-                None, None, None)
+        pg = T.accumulate_into_grads(ctx.all_params, (dW_w, dW_b, dU_w, dU_b, dA_w, dA_b, demb_w, dw_ih, dw_hh, db_g, db_g, dfc_w, dfc_b,
+                                                      dbn_g, dbn_b))
+        if pg[9] is not None and pg[10] is not None:
+            pg = pg[:10] + (db_g.clone(),) + pg[11:]          # autograd must not see one tensor as two gradients
+        return (dfeat,) + pg + (None, None, None)
 
 
 def decoder_train(mod, captions, feats, masks=None):

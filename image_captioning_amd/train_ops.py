@@ -36,10 +36,8 @@ def accumulate_into_grads(params, grads):
     multi-tensor add instead of autograd's one small add per parameter (213 of them for the EfficientNet) - and then runs
     the parameters' post-accumulate hooks, as autograd would have.  Returns the gradients still to be handed to autograd:
     None where the sum was taken here, grads[i] elsewhere (no buffer yet, other shape or dtype).
-    Used by the CNN's backward only, the last Function of the backward pass.  The same call from the decoder's and the encoder
-    block's backward (hooks then fire in the middle of the pass) made the two-rank rehearsal's parameters differ from the
-    single-process trainer's (tests/test_gpu_dp_rehearsal.py); the cause was not found, so those Functions still hand their
-    gradients to autograd."""
+    autograd runs the same hooks once more for the None it receives in place of such a gradient (observed on torch 2.10), so
+    hooks that count must ignore a parameter's second call within one backward pass (training.GradientReducer does)."""
     if not hasattr(torch.Tensor, "_post_accumulate_grad_hooks"):
         return tuple(grads)         # no way to run the hooks ourselves on this torch: leave every gradient to autograd
     dst, src, idx = [], [], []

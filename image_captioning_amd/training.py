@@ -318,6 +318,7 @@ class GradientReducer:
                     self.bucket_of[j] = b
                 idxs, hi = [], cur_lo
         self.pending = [0] * len(self.buckets)
+        self.fired = [False] * len(optimizer.params)
         self.counts = [0] * len(self.buckets)
         for j, b in self.bucket_of.items():
             self.counts[b] += 1
@@ -341,6 +342,12 @@ class GradientReducer:
             if not self.overlap:
                 return
             b = self.bucket_of[i]
+            # once per parameter and backward pass: a Function that adds its parameter gradients itself
+            # (train_ops.accumulate_into_grads) runs these hooks when the sums are in place, and autograd runs them a second
+            # time for the None it is handed - counted twice, a bucket shared with later parameters would leave early
+            if self.fired[i]:
+                return
+            self.fired[i] = True
             self.pending[b] += 1
             if self.pending[b] == self.counts[b]:
                 self.hooked += 1
@@ -363,6 +370,7 @@ class GradientReducer:
     def prepare(self):
         """Call before backward of every step."""
         self.pending = [0] * len(self.buckets)
+        self.fired = [False] * len(self.fired)
         self.launched = [False] * len(self.buckets)
         self.handles = []
         self.staged = []

@@ -276,80 +276,109 @@ int dwconv2d_stats_f32(const float* x, const float* w, float* y, int B, int H, i
 }
 
 // ---------------------------------------------------------------- squeeze-excite gate
-// One workgroup per image: pooled = sum of chunk partials / HW; s = swish(Wr pooled + br);
+// A workgroup owns SE_IMG images: pooled = sum of chunk partials / HW; s = swish(Wr pooled + br);
 // gate = sigmoid(We s + be).  Both weight matrices are stored [S][C] (the expand weight transposed) so that
-// every access is contiguous along the channel axis.
+// every access is contiguous along the channel axis.  Every weight element loaded is used for all SE_IMG images:
+// one image per workgroup re-read both matrices from L2 for each image (0.44 MB per image at C = 1152, S = 48,
+// 1.1 GB per launch at B = 1024 with the slices below).
 constexpr int SE_MAX_C = 2048;
 constexpr int SE_MAX_S = 128;
+constexpr int SE_IMG = 4;
+constexpr int SE_THREADS = 256 * SE_IMG;      // 256 threads pool one image each; all of them share the two matrix products
 
-__global__ __launch_bounds__(256) void se_gate_kernel(
+__global__ __launch_bounds__(SE_THREADS) void se_gate_kernel(
     const float* __restrict__ partial, int nchunks, float inv_hw, const float* __restrict__ wr,
     const float* __restrict__ br, const float* __restrict__ we, const float* __restrict__ be,
-    float* __restrict__ gate, int C, int S) {
-    __shared__ __attribute__((aligned(16))) float pooled[SE_MAX_C];
-    __shared__ float sq[SE_MAX_S];
-    __shared__ __attribute__((aligned(16))) float4 red[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    float* __restrict__ gate, int B, int C, int S) {
+    __shared__ __attribute__((aligned(16))) float pooled[SE_IMG][SE_MAX_C];
+    __shared__ float sq[SE_IMG][SE_MAX_S];
+    __shared__ __attribute__((aligned(16))) float4 red[SE_IMG][256];
+    const int b0 = blockIdx.x * SE_IMG, tid = threadIdx.x;
+    const int nimg = min(SE_IMG, B - b0);
     const int nq = C >> 2;
-    const float* pb = partial + (size_t)b * nchunks * C;
     // Pool: sum the chunk partials of every channel quad.  The 256 threads cover (quad, chunk lane) pairs;
     // with few channels and many chunks (early layers) several lanes split the chunk axis (interleaved) and
     // are combined through LDS in a fixed order, so the sum is independent of scheduling.
     int kl = 1;
     while (kl * 2 * nq <= 256 && kl * 2 <= nchunks) kl *= 2;
-    for (int q0 = 0; q0 < nq; q0 += 256 / kl) {
-        const int ql = tid % (256 / kl), l = tid / (256 / kl);
-        const int q = q0 + ql;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < nq) {
+    {
+        const int im = tid >> 8, t = tid & 255;            // image of this 256-thread group, thread within the group
+        const float* pb = partial + (size_t)(b0 + min(im, nimg - 1)) * nchunks * C;
+        for (int q0 = 0; q0 < nq; q0 += 256 / kl) {
+            const int ql = t % (256 / kl), l = t / (256 / kl);
+            const int q = q0 + ql;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < nq) {
 #pragma unroll 4
-            for (int k = l; k < nchunks; k += kl) {
-                const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)k * C + (q << 2));
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-        }
-        if (kl > 1) {
-            red[tid] = s;
-            __syncthreads();
-            if (l == 0 && q < nq) {
-                for (int j = 1; j < kl; ++j) {
-                    const float4 o = red[j * (256 / kl) + ql];
-                    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+                for (int k = l; k < nchunks; k += kl) {
+                    const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)k * C + (q << 2));
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 }
             }
-            __syncthreads();
-        }
-        if (l == 0 && q < nq) {
-            s.x *= inv_hw; s.y *= inv_hw; s.z *= inv_hw; s.w *= inv_hw;
-            *reinterpret_cast<float4*>(&pooled[q << 2]) = s;
+            if (kl > 1) {
+                red[im][t] = s;
+                __syncthreads();
+                if (l == 0 && q < nq) {
+                    for (int j = 1; j < kl; ++j) {
+                        const float4 o = red[im][j * (256 / kl) + ql];
+                        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+                    }
+                }
+                __syncthreads();
+            }
+            if (l == 0 && q < nq) {
+                s.x *= inv_hw; s.y *= inv_hw; s.z *= inv_hw; s.w *= inv_hw;
+                *reinterpret_cast<float4*>(&pooled[im][q << 2]) = s;
+            }
         }
     }
     __syncthreads();
-    // Squeeze: one wave per output j, 16-byte weight loads, several j in flight per wave.
+    // Squeeze: one wave per output j, 16-byte weight loads, each used for all images of the workgroup.
     const int wave = tid >> 6, lane = tid & 63;
-    for (int j = wave; j < S; j += 4) {
-        float a = 0.f;
+    for (int j = wave; j < S; j += SE_THREADS / 64) {
+        float a[SE_IMG];
+#pragma unroll
+        for (int im = 0; im < SE_IMG; ++im) a[im] = 0.f;
         const float* wj = wr + (size_t)j * C;
-#pragma unroll 4
-        for (int q = lane; q < nq; q += 64)
-            a = dot4(*reinterpret_cast<const float4*>(wj + (q << 2)), *reinterpret_cast<const float4*>(&pooled[q << 2]), a);
-        a = wave_sum(a);
-        if (lane == 0) sq[j] = act_apply(a + br[j], ACT_SWISH);
+#pragma unroll 2
+        for (int q = lane; q < nq; q += 64) {
+            const float4 wv = *reinterpret_cast<const float4*>(wj + (q << 2));
+#pragma unroll
+            for (int im = 0; im < SE_IMG; ++im) a[im] = dot4(wv, *reinterpret_cast<const float4*>(&pooled[im][q << 2]), a[im]);
+        }
+        const float bj = br[j];
+#pragma unroll
+        for (int im = 0; im < SE_IMG; ++im) {
+            const float t = wave_sum(a[im]);
+            if (lane == 0) sq[im][j] = act_apply(t + bj, ACT_SWISH);
+        }
     }
     __syncthreads();
-    // Excite: this workgroup's slice of the channel quads (gridDim.y slices per image).
+    // Excite: this workgroup's slice of the channel quads (gridDim.y slices per image group).
     const int per = (nq + gridDim.y - 1) / gridDim.y;
     const int q_lo = blockIdx.y * per, q_hi = min(nq, q_lo + per);
-    for (int q = q_lo + tid; q < q_hi; q += 256) {
-        float4 a = *reinterpret_cast<const float4*>(be + (q << 2));
-#pragma unroll 8
+    for (int q = q_lo + tid; q < q_hi; q += SE_THREADS) {
+        const float4 bq = *reinterpret_cast<const float4*>(be + (q << 2));
+        float4 a[SE_IMG];
+#pragma unroll
+        for (int im = 0; im < SE_IMG; ++im) a[im] = bq;
+#pragma unroll 4
         for (int j = 0; j < S; ++j) {
             const float4 wv = *reinterpret_cast<const float4*>(we + (size_t)j * C + (q << 2));
-            const float sj = sq[j];
-            a.x = fmaf(wv.x, sj, a.x); a.y = fmaf(wv.y, sj, a.y); a.z = fmaf(wv.z, sj, a.z); a.w = fmaf(wv.w, sj, a.w);
+#pragma unroll
+            for (int im = 0; im < SE_IMG; ++im) {
+                const float sj = sq[im][j];
+                a[im].x = fmaf(wv.x, sj, a[im].x); a[im].y = fmaf(wv.y, sj, a[im].y);
+                a[im].z = fmaf(wv.z, sj, a[im].z); a[im].w = fmaf(wv.w, sj, a[im].w);
+            }
         }
-        a.x = sigmoidf_(a.x); a.y = sigmoidf_(a.y); a.z = sigmoidf_(a.z); a.w = sigmoidf_(a.w);
-        *reinterpret_cast<float4*>(gate + (size_t)b * C + (q << 2)) = a;
+#pragma unroll
+        for (int im = 0; im < SE_IMG; ++im) {
+            if (im >= nimg) break;
+            float4 o = a[im];
+            o.x = sigmoidf_(o.x); o.y = sigmoidf_(o.y); o.z = sigmoidf_(o.z); o.w = sigmoidf_(o.w);
+            *reinterpret_cast<float4*>(gate + (size_t)(b0 + im) * C + (q << 2)) = o;
+        }
     }
 }
 
@@ -364,11 +393,12 @@ int se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr
         set_error("se_gate: C %% 4 and 16-byte alignment required");
         return ICAP_ERR_ALIGN;
     }
-    if (B > 65535) { set_error("se_gate: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
-    // several workgroups per image when there are enough channels to share out (each recomputes the cheap
-    // pooled / squeeze vectors and writes its own slice of the gate)
-    const int slices = C >= 960 ? 4 : (C >= 384 ? 2 : 1);
-    hipLaunchKernelGGL(se_gate_kernel, dim3(B, slices), dim3(256), 0, st, partial, nchunks, inv_hw, wr, br, we, be, gate, C, S);
+    const int groups = (B + SE_IMG - 1) / SE_IMG;
+    // several workgroups per image group when there are enough channels to share out and few groups (each recomputes the
+    // cheap pooled / squeeze vectors and writes its own slice of the gate)
+    int slices = C >= 960 ? 4 : (C >= 384 ? 2 : 1);
+    while (slices < 8 && groups * slices < 256 && (C >> 2) / (slices * 2) >= 32) slices *= 2;
+    hipLaunchKernelGGL(se_gate_kernel, dim3(groups, slices), dim3(SE_THREADS), 0, st, partial, nchunks, inv_hw, wr, br, we, be, gate, B, C, S);
     return launch_status("se_gate");
 }
 

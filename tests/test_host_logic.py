@@ -200,3 +200,29 @@ def test_accumulate_into_grads_adds_in_one_call_and_runs_the_hooks():
     assert flat.touched == [True, True] and len(fired) == 1 and fired[0] is ps[1]
     assert torch.equal(ps[0].grad, torch.full((3, 4), 2.0)) and torch.equal(ps[1].grad, torch.full((5,), 3.0))
     assert ps[0].grad.data_ptr() == flat.flat_g.data_ptr()          # still the flat buffer's view
+
+
+def test_reducer_hooks_count_a_parameter_once_per_backward_pass():
+    """A Function that adds its own parameter gradients runs the post-accumulate hooks itself and autograd runs them again
+    for the None it receives: the bucket bookkeeping must not count the second call, or a bucket shared with parameters
+    whose gradients come later would be exchanged early."""
+    import torch
+    from image_captioning_amd.training import FlatParameters, GradientReducer
+    ps = [torch.nn.Parameter(torch.randn(8)) for _ in range(4)]
+    flat = FlatParameters(ps)
+    red = GradientReducer(flat, bucket_mb=16 * 4 / (1 << 20))      # 16 floats per bucket: two parameters each
+    assert len(red.buckets) == 2 and red.counts == [2, 2]
+    launched = []
+    red.overlap = True                                              # single process: drive the bookkeeping by hand
+    red._launch = lambda b: launched.append(b)
+    hooks = [red._make_hook(i) for i in range(4)]
+    red.prepare()
+    hooks[3](ps[3]); hooks[3](ps[3])                               # the same parameter twice: counted once
+    assert launched == [] and red.pending[red.bucket_of[3]] == 1
+    hooks[2](ps[2])
+    assert launched == [red.bucket_of[3]] and red.bucket_of[2] == red.bucket_of[3]
+    hooks[2](ps[2]); hooks[3](ps[3])
+    assert launched == [red.bucket_of[3]]                          # no second launch
+    red.prepare()                                                   # next step: counted afresh
+    hooks[3](ps[3]); hooks[2](ps[2])
+    assert launched == [red.bucket_of[3]] * 2

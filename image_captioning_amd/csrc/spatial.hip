@@ -354,31 +354,21 @@ __global__ __launch_bounds__(SE_THREADS) void se_gate_kernel(
         }
     }
     __syncthreads();
-    // Excite: this workgroup's slice of the channel quads (gridDim.y slices per image group).
+    // Excite: this workgroup's slice of the channel quads (gridDim.y slices per image group); a thread owns one
+    // (image, quad) pair, so that the 1024 threads have work even when the slice is a few hundred quads wide.
     const int per = (nq + gridDim.y - 1) / gridDim.y;
-    const int q_lo = blockIdx.y * per, q_hi = min(nq, q_lo + per);
-    for (int q = q_lo + tid; q < q_hi; q += SE_THREADS) {
-        const float4 bq = *reinterpret_cast<const float4*>(be + (q << 2));
-        float4 a[SE_IMG];
-#pragma unroll
-        for (int im = 0; im < SE_IMG; ++im) a[im] = bq;
-#pragma unroll 4
+    const int q_lo = blockIdx.y * per, q_hi = min(nq, q_lo + per), nqs = max(q_hi - q_lo, 0);
+    for (int wi = tid; wi < nimg * nqs; wi += SE_THREADS) {
+        const int im = wi / nqs, q = q_lo + (wi - im * nqs);
+        float4 a = *reinterpret_cast<const float4*>(be + (q << 2));
+#pragma unroll 8
         for (int j = 0; j < S; ++j) {
             const float4 wv = *reinterpret_cast<const float4*>(we + (size_t)j * C + (q << 2));
-#pragma unroll
-            for (int im = 0; im < SE_IMG; ++im) {
-                const float sj = sq[im][j];
-                a[im].x = fmaf(wv.x, sj, a[im].x); a[im].y = fmaf(wv.y, sj, a[im].y);
-                a[im].z = fmaf(wv.z, sj, a[im].z); a[im].w = fmaf(wv.w, sj, a[im].w);
-            }
+            const float sj = sq[im][j];
+            a.x = fmaf(wv.x, sj, a.x); a.y = fmaf(wv.y, sj, a.y); a.z = fmaf(wv.z, sj, a.z); a.w = fmaf(wv.w, sj, a.w);
         }
-#pragma unroll
-        for (int im = 0; im < SE_IMG; ++im) {
-            if (im >= nimg) break;
-            float4 o = a[im];
-            o.x = sigmoidf_(o.x); o.y = sigmoidf_(o.y); o.z = sigmoidf_(o.z); o.w = sigmoidf_(o.w);
-            *reinterpret_cast<float4*>(gate + (size_t)(b0 + im) * C + (q << 2)) = o;
-        }
+        a.x = sigmoidf_(a.x); a.y = sigmoidf_(a.y); a.z = sigmoidf_(a.z); a.w = sigmoidf_(a.w);
+        *reinterpret_cast<float4*>(gate + (size_t)(b0 + im) * C + (q << 2)) = a;
     }
 }
 
@@ -394,9 +384,9 @@ int se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr
         return ICAP_ERR_ALIGN;
     }
     const int groups = (B + SE_IMG - 1) / SE_IMG;
-    // several workgroups per image group when there are enough channels to share out and few groups (each recomputes the
-    // cheap pooled / squeeze vectors and writes its own slice of the gate)
-    int slices = C >= 960 ? 4 : (C >= 384 ? 2 : 1);
+    // several workgroups per image group only when the groups alone leave CUs idle (each recomputes the pooled / squeeze
+    // vectors and writes its own slice of the gate)
+    int slices = 1;
     while (slices < 8 && groups * slices < 256 && (C >> 2) / (slices * 2) >= 32) slices *= 2;
     hipLaunchKernelGGL(se_gate_kernel, dim3(groups, slices), dim3(SE_THREADS), 0, st, partial, nchunks, inv_hw, wr, br, we, be, gate, B, C, S);
     return launch_status("se_gate");

@@ -32,7 +32,6 @@ MAX_LOCKSTEP = 8
 # more rows, but a single dependent phase) and the table stays small
 TABLE_MAX_VOCAB_PER_STEP = 2
 TABLE_MAX_ROWS = 1 << 17
-_TABLE_TOKENS: dict = {}
 
 
 def _f32(t):
@@ -252,10 +251,7 @@ class ImageCaptioningModelBase(nn.Module):
         after the other, without their max_len sequential launches."""
         B, E = ca.shape
         V = wd["out_w"].shape[0]
-        key = (V, B, str(ca.device))
-        tok = _TABLE_TOKENS.get(key)
-        if tok is None:
-            tok = _TABLE_TOKENS[key] = torch.arange(V, device=ca.device, dtype=torch.int64).repeat_interleave(B).contiguous()
+        tok = torch.arange(V, device=ca.device, dtype=torch.int64).repeat_interleave(B)     # one small launch; nothing is kept per batch size
         rows, _ = ops.embedding(wd["emb"], tok)                                       # row v*B + b = emb[v]
         x = ops.layernorm(rows, wd["ln2_g"], wd["ln2_b"], res=ca)                     # residual row (v*B + b) % B = ca[b]
         h = ops.linear(x, wd["fc1_w"], wd["fc1_b"], act=ops.ACT_RELU)

@@ -1079,9 +1079,12 @@ def greedy_tfm_persist_max_nb(E: int, FF: int, V: int) -> int:
     return N.load().icap_greedy_tfm_persist_max_nb(E, FF, V)
 
 
-def greedy_tfm_persist(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False):
-    """greedy_tfm as one persistent launch with LDS-resident weights (icap_greedy_tfm_persist_f32).  A launch that could
-    not make progress leaves -1 in every id."""
+def greedy_tfm_persist(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False, check=True):
+    """greedy_tfm as one persistent launch with LDS-resident weights (icap_greedy_tfm_persist_f32).  The kernel needs all
+    its workgroups resident at once (a plain launch: a kernel running beside it on another stream, or a CU-masked device,
+    breaks that); a launch that could not make progress gives up after a bounded spin and leaves -1 in every id.  With
+    check=True (the default) the ids are read back - one host synchronisation - and such a launch raises IcapError
+    instead of returning -1 as if it were a caption; check=False leaves the test to the caller."""
     lib = N.load()
     NB, E = ca.shape
     FF = wd["fc1_w"].shape[0]
@@ -1097,6 +1100,9 @@ def greedy_tfm_persist(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, step
     N.check(lib.icap_greedy_tfm_persist_f32(C.byref(w), _ck(ca, "ca"), _ck(start_ids, "start_ids", torch.int64),
                                             _ck(ids, "ids", torch.int64), _ck(logits, "logits"), ws.data_ptr(), NB, steps, _stream()),
             "greedy_tfm_persist")
+    if check and bool((ids < 0).any().item()):
+        raise IcapError("greedy_tfm_persist: the persistent launch could not make progress (its workgroups were not all resident); "
+                        "use greedy_tfm")
     return ids, logits
 
 

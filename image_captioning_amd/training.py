@@ -277,12 +277,17 @@ class GradientReducer:
     the mean of the per-rank mean losses.  Buckets are contiguous slices of the flat gradient, filled in reverse
     parameter order by backward.
 
-    ``overlap=True`` (the default): post-accumulate hooks launch the all-reduce of a bucket as soon as its last
+    ``overlap=True``: post-accumulate hooks launch the all-reduce of a bucket as soon as its last
     gradient has been accumulated, so the exchange of the late layers' gradients runs while backward is still working
     on the early layers (collectives are launched from autograd's worker thread, in the same order on every rank because
     every rank runs the same graph); ``finish`` launches whatever the hooks did not (buckets holding parameters without
     a gradient this step) and makes the launch stream wait for all of them.  ``overlap=False`` reduces every bucket in
-    ``finish``, after backward.
+    ``finish``, after backward, from the thread that called ``step``.  ``overlap=None`` (the default) picks by backend:
+    True for gloo, whose hook path is exercised by the two-rank tests, and False for RCCL ("nccl") unless the
+    environment sets ICAP_DP_OVERLAP=1 - the hook path HAS NOT YET RUN OVER RCCL on real multi-GPU hardware (collectives
+    launched from autograd's worker thread, ordering of the process group's stream against the launch stream through
+    ``wait``), so it stays opt-in there; ``overlap`` may also be switched between steps (the hooks are always
+    registered and look at the flag).
 
     Backends.  RCCL ("nccl"): ``all_reduce(async_op=True)`` runs on the process group's own stream, ordered after the
     stream current at the call, and ``wait`` orders the current stream after it - no host blocking, no extra stream
@@ -293,7 +298,8 @@ class GradientReducer:
     CPU tensors (the gloo unit tests) go to gloo directly.
     """
 
-    def __init__(self, flat, group=None, bucket_mb: float = 16.0, overlap: bool = True):
+    def __init__(self, flat, group=None, bucket_mb: float = 16.0, overlap=None):
+        import os
         import torch.distributed as dist
         self.dist = dist
         optimizer = flat.flat if isinstance(flat, (AdamW, SGD)) else flat
@@ -323,9 +329,11 @@ class GradientReducer:
         for j, b in self.bucket_of.items():
             self.counts[b] += 1
         self.handles = []
-        self.overlap = overlap and self.world > 1
         on_device = optimizer.flat_g.is_cuda
         backend = dist.get_backend(group) if dist.is_initialized() else ""
+        if overlap is None:
+            overlap = backend != "nccl" or os.environ.get("ICAP_DP_OVERLAP") == "1"
+        self.overlap = bool(overlap) and self.world > 1
         self.host_staged = on_device and self.world > 1 and backend == "gloo"
         self.comm_stream = torch.cuda.Stream() if self.host_staged else None
         self.host = [torch.empty(hi - lo, dtype=torch.float32).pin_memory() for lo, hi in self.buckets] if self.host_staged else None
@@ -333,7 +341,7 @@ class GradientReducer:
         self.launched = [False] * len(self.buckets)
         self.launch_order = []     # bucket indices in the order their exchange was launched this step (tests, diagnostics)
         self.hooked = 0            # how many of them were launched by hooks, i.e. while backward was still running
-        if self.overlap:
+        if self.world > 1:
             for i, p in enumerate(optimizer.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -422,8 +430,8 @@ class Trainer:
         self.opt = AdamW(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         if self.graph and overlap:
             raise ValueError("Trainer(graph=True): the gradient exchange runs between the two recorded graphs; overlap=True is not supported")
-        if overlap is None:                  # overlapped exchange unless the step is replayed from graphs (hooks do not run in a replay)
-            overlap = not self.graph
+        if overlap is None and self.graph:   # hooks do not run in a replay; otherwise the reducer picks by backend
+            overlap = False
         self.reducer = GradientReducer(self.opt, group=group, bucket_mb=bucket_mb, overlap=overlap) if dist.is_available() and dist.is_initialized() else None
         self.loss_kind = loss
 

@@ -70,6 +70,9 @@ SIGNATURES = {
     "icap_expand_dwconv_chunks": (_i, [_i] * 6),
     "icap_expand_dwconv_whole_image": (_i, [_i] * 6),
     "icap_expand_dwconv_f32x3_f32": (_i, [_p] * 9 + [_i] * 11 + [_p]),
+    "icap_expand_dwconv_img_x3_we_bytes": (_ll, [_i] * 5),
+    "icap_expand_dwconv_img_x3_pack": (_i, [_p, _p] + [_i] * 5 + [_p]),
+    "icap_expand_dwconv_img_x3_f32": (_i, [_p] * 9 + [_i] * 8 + [_p]),
     "icap_stem_dwconv_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),
     "icap_stem_dwconv_chunks": (_i, [_i] * 3),
     "icap_expand_dwconv_bf16_f32": (_i, [_p] * 8 + [_i, _p] + [_i] * 11 + [_p]),

@@ -350,7 +350,7 @@ class EfficientNetB0(nn.Module):
                 # early blocks: the 6x expanded activations stay on chip between the 1x1 and the depthwise convolution
                 h, part = ops.expand_dwconv2d(h, d["expand"][0], *d["expand"][1], d["dw_w"], *d["dw_sb"], ks=d["k"],
                                               stride=d["stride"], pad=pad, want_partial=True,
-                                              out_bf16=ops.bf16_activations_ok(d["dw_w"].shape[1], d["proj"][0].shape[0]))
+                                              out_bf16=ops.bf16_activations_ok(d["dw_w"].shape[1], d["proj"][0].shape[0]), cache=d)
             else:
                 if d["expand"] is not None:
                     h = ops.pointwise_conv(h, d["expand"][0], d, "expand16", *d["expand"][1], act=ops.ACT_SWISH)

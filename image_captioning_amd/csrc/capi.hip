@@ -68,6 +68,10 @@ int expand_dwconv_f32(const float*, const float*, const float*, const float*, co
                       float*, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int expand_dwconv_chunks(int, int, int, int, int, int);
 int expand_dwconv_whole_image(int, int, int, int, int, int);
+long long expand_dwconv_img_x3_we_bytes(int, int, int, int, int);
+int expand_dwconv_img_x3_pack(const float*, void*, int, int, int, int, int, hipStream_t);
+int expand_dwconv_img_x3_f32(const float*, const void*, const float*, const float*, const float*, const float*, const float*, float*,
+                             float*, int, int, int, int, int, int, int, int, hipStream_t);
 int stem_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                     float*, int, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int stem_dwconv_chunks(int, int, int);
@@ -328,6 +332,21 @@ int icap_expand_dwconv_chunks(int Ho, int Wo, int Cin, int Cexp, int KS, int str
 
 int icap_expand_dwconv_whole_image(int H, int W, int Cin, int Cexp, int KS, int stride) {
     return expand_dwconv_whole_image(H, W, Cin, Cexp, KS, stride);
+}
+
+long long icap_expand_dwconv_img_x3_we_bytes(int H, int W, int Cin, int Cexp, int KS) {
+    return expand_dwconv_img_x3_we_bytes(H, W, Cin, Cexp, KS);
+}
+
+int icap_expand_dwconv_img_x3_pack(const float* w_exp, void* w_packed, int H, int W, int Cin, int Cexp, int KS, void* stream) {
+    return expand_dwconv_img_x3_pack(w_exp, w_packed, H, W, Cin, Cexp, KS, (hipStream_t)stream);
+}
+
+int icap_expand_dwconv_img_x3_f32(const float* x, const void* w_packed, const float* exp_scale, const float* exp_bias, const float* w_dw,
+                                  const float* dw_scale, const float* dw_bias, float* y, float* pooled, int B, int H, int W, int Cin,
+                                  int Cexp, int KS, int pad_t, int pad_l, void* stream) {
+    return expand_dwconv_img_x3_f32(x, w_packed, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, y, pooled, B, H, W, Cin, Cexp, KS, pad_t,
+                                    pad_l, (hipStream_t)stream);
 }
 
 int icap_se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr, const float* br, const float* we,

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void expand_dw_img_kernel(const float* __re
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int row = (2 * wave + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        const float v = acc[i][j][e] * s_[j] + b_[j];
+                        const float v = fmaf(acc[i][j][e], s_[j], b_[j]);
                         if (row < XL_ROWS) E[row * XL_ES + 32 * j + lr] = v * sigmoid_fast(v);
                     }
             }
@@ -195,10 +195,10 @@ __global__ __launch_bounds__(256, 2) void expand_dw_img_kernel(const float* __re
                 for (int dc = 0; dc < KS; ++dc) {
                     const int cc = c + dc - PAD;
                     if (cc >= 0 && cc < HW) {
-                        o[c].x += ev[cc].x * w[dc].x;
-                        o[c].y += ev[cc].y * w[dc].y;
-                        o[c].z += ev[cc].z * w[dc].z;
-                        o[c].w += ev[cc].w * w[dc].w;
+                        o[c].x = fmaf(ev[cc].x, w[dc].x, o[c].x);      // explicit: the library is built without contraction
+                        o[c].y = fmaf(ev[cc].y, w[dc].y, o[c].y);
+                        o[c].z = fmaf(ev[cc].z, w[dc].z, o[c].z);
+                        o[c].w = fmaf(ev[cc].w, w[dc].w, o[c].w);
                     }
                 }
         }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void expand_dw_img_kernel(const float* __re
 #pragma unroll
         for (int c = 0; c < HW; ++c) {
             float4 v;
-            v.x = o[c].x * dsv.x + dbv.x; v.y = o[c].y * dsv.y + dbv.y; v.z = o[c].z * dsv.z + dbv.z; v.w = o[c].w * dsv.w + dbv.w;
+            v.x = fmaf(o[c].x, dsv.x, dbv.x); v.y = fmaf(o[c].y, dsv.y, dbv.y); v.z = fmaf(o[c].z, dsv.z, dbv.z); v.w = fmaf(o[c].w, dsv.w, dbv.w);
             v.x *= sigmoid_fast(v.x); v.y *= sigmoid_fast(v.y); v.z *= sigmoid_fast(v.z); v.w *= sigmoid_fast(v.w);
             if (st_ok) *reinterpret_cast<float4*>(dst + (size_t)c * Cexp) = v;
             ps.x += v.x; ps.y += v.y; ps.z += v.z; ps.w += v.w;

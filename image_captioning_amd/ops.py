@@ -538,9 +538,14 @@ def expand_dwconv_supported(H, W, Cin, Cexp, ks, stride, pad) -> bool:
                                          Cin, Cexp, ks, stride) > 0
 
 
+IMG_X3 = True      # "f32x3" mode: the whole-image layer shapes on icap_expand_dwconv_img_x3_f32 (False: the fp32 whole-image kernel)
+
+
 def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, ks, stride=1, pad=(0, 0, 0, 0), want_partial=False,
-                    out_bf16=False):
-    """x [B,H,W,Cin], w_exp [Cexp,1,1,Cin] or [Cexp,Cin], w_dw [ks*ks, Cexp] -> (swish(bn(dw(swish(bn(expand(x)))))), partial)."""
+                    out_bf16=False, cache=None, key="expand_x3p"):
+    """x [B,H,W,Cin], w_exp [Cexp,1,1,Cin] or [Cexp,Cin], w_dw [ks*ks, Cexp] -> (swish(bn(dw(swish(bn(expand(x)))))), partial).
+    cache / key: where the packed split weights of the whole-image split-product kernel are kept between calls (a dict
+    that lives as long as the weight, e.g. the layer's prepared-weights entry); without it they are packed per call."""
     B, H, W, Cin = x.shape
     Cexp = w_exp.shape[0]
     pt, pb, pl, pr = pad
@@ -564,6 +569,16 @@ def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, k
     tail = (_ck(partial, "partial"), B, H, W, Cin, Cexp, ks, stride, pt, pl, Ho, Wo, _stream())
     if bf16:
         N.check(lib.icap_expand_dwconv_bf16_f32(*head, _ck(y, "y", ydt), int(out_bf16), *tail), "expand_dwconv2d")
+    elif (COMPUTE_DTYPE == "f32x3" and IMG_X3 and stride == 1 and (pt, pl) == (ks // 2, ks // 2)
+          and lib.icap_expand_dwconv_img_x3_we_bytes(H, W, Cin, Cexp, ks) > 0):
+        wp = cache.get(key) if cache is not None else None
+        if wp is None:
+            wp = torch.empty(lib.icap_expand_dwconv_img_x3_we_bytes(H, W, Cin, Cexp, ks) // 2, device=x.device, dtype=torch.bfloat16)
+            N.check(lib.icap_expand_dwconv_img_x3_pack(_ck(w_exp, "w_exp"), wp.data_ptr(), H, W, Cin, Cexp, ks, _stream()), "expand_dwconv2d pack")
+            if cache is not None:
+                cache[key] = wp
+        N.check(lib.icap_expand_dwconv_img_x3_f32(head[0], wp.data_ptr(), *head[2:], _ck(y, "y"), _ck(partial, "partial"), B, H, W, Cin,
+                                                  Cexp, ks, pt, pl, _stream()), "expand_dwconv2d")
     elif COMPUTE_DTYPE == "f32x3":
         N.check(lib.icap_expand_dwconv_f32x3_f32(*head, _ck(y, "y"), *tail), "expand_dwconv2d")
     else:

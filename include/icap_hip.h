@@ -135,6 +135,20 @@ int icap_expand_dwconv_f32x3_f32(const float* x, const float* w_exp, const float
                                  int B, int H, int W, int Cin, int Cexp, int KS, int stride, int pad_t, int pad_l, int Ho,
                                  int Wo, void* stream);
 
+/* The whole-image layer shapes of icap_expand_dwconv_whole_image with split products AND the depthwise stage of one
+ * channel chunk issued between the matrix instructions of the next chunk (one wave per SIMD keeps the split input planes
+ * of its pixels in registers for the workgroup's life; vector work inside a wave's own MFMA stream runs in the matrix
+ * instruction's shadow).  The expand weights come pre-split and packed in fragment order: icap_expand_dwconv_img_x3_pack
+ * writes icap_expand_dwconv_img_x3_we_bytes(...) bytes (0 = no such kernel for this shape) from w_exp [Cexp][Cin], once
+ * per weight.  Same result as icap_expand_dwconv_f32x3_f32 / icap_expand_dwconv_f32 to a few fp32 roundings; `pooled`
+ * [B][Cexp] = per-image channel sums or NULL; pad must be KS / 2.  Same reference lines as icap_expand_dwconv_f32
+ * (MBConv `_expand_conv` ... swish of EfficientNet-B0, transformer_word_level.py:13). */
+long long icap_expand_dwconv_img_x3_we_bytes(int H, int W, int Cin, int Cexp, int KS);
+int icap_expand_dwconv_img_x3_pack(const float* w_exp, void* w_packed, int H, int W, int Cin, int Cexp, int KS, void* stream);
+int icap_expand_dwconv_img_x3_f32(const float* x, const void* w_packed, const float* exp_scale, const float* exp_bias,
+                                  const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* pooled,
+                                  int B, int H, int W, int Cin, int Cexp, int KS, int pad_t, int pad_l, void* stream);
+
 /* The two fused kernels with bf16 products in their first (expand / stem) convolution - operands rounded to bf16 in
  * registers, fp32 accumulation on v_mfma_f32_32x32x16_bf16; the depthwise stage computes in fp32.  y is fp32
  * (y_bf16 = 0) or a bf16 tensor of the same shape (y_bf16 = 1, round to nearest even; the squeeze-excite partial sums

@@ -53,9 +53,10 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="training mode: record the step into HIP graphs (Trainer(graph=True); pays at small batches)")
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the secondary bf16-mode measurement")
+    ap.add_argument("--no-plain-f32", action="store_true", help="skip the secondary plain-fp32 measurement of the captioning step")
     ap.add_argument("--no-train-mode", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--train-batch", type=int, default=256, help="images per step per GPU of the secondary training measurement")
-    ap.add_argument("--train-deadline", type=float, default=240.0,
+    ap.add_argument("--train-deadline", type=float, default=300.0,
                     help="seconds the secondary training measurement may take before the line is printed without it")
     ap.add_argument("--batch", type=int, default=None, help="images per step per GPU (default 1024 captioning, 256 training)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-launch time table of one step and exit")
@@ -192,6 +193,39 @@ def step_roofline(rec, step_ms):
     }
 
 
+def traced_step_roofline(torch, ops, step, step_ms, phase="train"):
+    """One more step with an event pair around every traced launch (events on the launch stream) -> the `roofline` object of
+    that step: the launch shape with the largest accumulated time priced against its binding roofline, plus
+    step / phases / worst for the whole step (step_ms: the step time measured without events)."""
+    rec = []
+    PHASE[0] = phase
+    ops.set_trace(lambda n, sg: rec.append((PHASE[0], n, sg, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))) or rec[-1][3:])
+    step()
+    torch.cuda.synchronize()
+    ops.set_trace(None)
+    rows = [(ph, n, sg, e0.elapsed_time(e1)) for ph, n, sg, e0, e1 in rec]
+    agg = {}
+    for _, n, sg, ms in rows:
+        a = agg.setdefault((n, sg), [0.0, 0])
+        a[0] += ms
+        a[1] += 1
+    (n, sg), (tot, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+    dom_ms = tot / cnt
+    flops, byts = WORK[n](sg)
+    peak = mfma_peak_for(n)
+    if byts / (HBM_PEAK_GBS * 1e9) >= flops / (peak * 1e12):
+        roof = {"bound": "hbm", "achieved": byts / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    else:
+        roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["kernel"] = f"{n}{list(sg)}"
+    roof["launches_per_step"] = cnt
+    roof["avg_launch_ms"] = dom_ms
+    roof["traffic"] = pmc_traffic(roof["kernel"])
+    roof.update(step_roofline(rows, step_ms))
+    return roof
+
+
 # ---------------------------------------------------------------- verification of what was timed
 GAP_EXEMPT = 1e-4      # ids may differ only from a step on whose top-2 logit gap is below this (BASELINE north_star)
 
@@ -243,18 +277,35 @@ def verify_caption(torch, ops, model, images, ids_timed, n_oracle=16):
     return res
 
 
-def verify_train(torch, ops, dev, rank, B, loss_tuned, seed_state):
-    """The training secondary's first step ran tuned tile configurations (and, in f32x3 mode, split-product GEMMs): the same
-    step (same weights, inputs, dropout seed) in plain fp32 on the untuned configurations must give the same loss."""
+def verify_train(torch, ops, dev, rank, B, tuned, seed_state):
+    """The training secondary's first steps ran tuned tile configurations (and, in f32x3 mode, split-product GEMMs) in the
+    forward pass, the backward pass, the weight-gradient GEMMs and AdamW.  The same three steps (same weights, inputs,
+    dropout seed) in plain fp32 on the untuned configurations must give the same loss at step 1 (forward), the same norm
+    of the flat gradient after step 1 (backward and weight gradients) and the same loss at step 3 (two optimizer updates
+    later).  tuned = {"loss1", "grad_norm1", "loss3"} of the timed trainer."""
     from image_captioning_amd._bah_train import DropoutState
     with ops.untuned():
         _, step = build_train_step(torch, dev, rank, B)
         DropoutState.manual_seed(seed_state)
-        loss_u = float(step())
+        loss1 = float(step())
+        gn1 = float(step.trainer.opt.flat.flat_g.double().norm().item())
+        step()
+        loss3 = float(step())
     del step
     torch.cuda.empty_cache()
-    rel = abs(loss_u - loss_tuned) / max(abs(loss_u), 1e-12)
-    return {"loss_tuned": loss_tuned, "loss_untuned": loss_u, "rel_diff": rel, "ok": rel < 1e-4}
+
+    def rel(a, b):
+        return abs(a - b) / max(abs(b), 1e-12)
+    r1, rg, r3 = rel(tuned["loss1"], loss1), rel(tuned["grad_norm1"], gn1), rel(tuned["loss3"], loss3)
+    return {"loss_tuned": tuned["loss1"], "loss_untuned": loss1, "rel_diff": r1,
+            "grad_norm_step1_tuned": tuned["grad_norm1"], "grad_norm_step1_untuned": gn1, "grad_norm_rel_diff": rg,
+            "loss_step3_tuned": tuned["loss3"], "loss_step3_untuned": loss3, "loss_step3_rel_diff": r3,
+            "tolerances": {"loss_step1": 1e-4, "grad_norm_step1": TRAIN_VERIFY_GRAD_TOL, "loss_step3": TRAIN_VERIFY_LOSS3_TOL},
+            "ok": r1 < 1e-4 and rg < TRAIN_VERIFY_GRAD_TOL and r3 < TRAIN_VERIFY_LOSS3_TOL}
+
+
+TRAIN_VERIFY_GRAD_TOL = 2e-3      # norm of all 16.6 M gradients, split-product (fp32-accurate) against plain fp32 products
+TRAIN_VERIFY_LOSS3_TOL = 5e-4     # loss after two AdamW updates
 
 
 # ---------------------------------------------------------------- one caption at a time (weight-streaming decode steps)
@@ -311,6 +362,12 @@ def decode_b1(torch, dev):
         gbs = DECODE_PARAMS[name] * 4 / us / 1e3
         out[name] = {"us_per_step": us, "steps": steps, "captions_per_s": 1e3 / ms, "bytes_per_step": DECODE_PARAMS[name] * 4,
                      "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "mode": modes[name]}
+        if name == "char_transformer":
+            # the table path reads the weights once per CAPTION (one batched pass over the 81 tokens), not once per step: its
+            # figure of merit is captions/s; the bandwidth fraction of the char model is that of the step-by-step forms below
+            for k in ("bytes_per_step", "achieved_gbs", "hbm_frac"):
+                del out[name][k]
+            out[name]["us_per_step_equivalent"] = out[name].pop("us_per_step")
     # bf16 weight streaming (icap_greedy_*_w16_f32): the weight matrices are read as bf16 copies, everything else stays fp32
     from image_captioning_amd import ops as _ops
     _ops.set_decode_weights("bf16")
@@ -326,18 +383,25 @@ def decode_b1(torch, dev):
     finally:
         _ops.set_decode_weights(None)
     # the char model step by step, for comparison with its table path: the step-per-launch driver and the persistent launch
-    for mode in ("steps", "persistent"):
+    for mode, label in (("steps", "step_by_step"), ("persistent", "persistent")):
         ms = timeit(lambda: cm.greedy_ids_from_features(f512, 58, mode=mode))
-        out["char_transformer"][f"us_per_step_{mode}"] = ms * 1e3 / 58
+        us = ms * 1e3 / 58
+        gbs = DECODE_PARAMS["char_transformer"] * 4 / us / 1e3
+        out["char_transformer"][label] = {"us_per_step": us, "bytes_per_step": DECODE_PARAMS["char_transformer"] * 4, "achieved_gbs": gbs,
+                                         "hbm_frac": gbs / HBM_PEAK_GBS}
     out["note"] = ("one caption in flight, fp32 weights, whole caption enqueued without host round trips; bytes = parameters touched per step x 4; "
-                   "us_per_step of the char model's table path = caption time / 58 (its weights are read once per caption, not per step)")
+                   "the char model's default (table) path is reported as captions/s and us per step-equivalent (caption time / 58): its weights are read once per caption; its bandwidth figures are those of the step-by-step forms (steps: one launch chain per step; persistent: one launch per caption)")
     return out
 
 
 
-CAPTION_DTYPES = {"f32": "f32",
-                  "f32x3": "f32 (fp32-accurate: the MFMA-bound GEMMs as six exact bf16 products per multiply from three-way operand splits, "
-                           "fp32 accumulate; every other kernel plain fp32; fp32 tensors)"}
+CAPTION_DTYPES = {"f32": "f32", "f32x3": "f32x3"}
+DTYPE_NOTES = {"f32": "every product on the fp32 matrix-core instruction, fp32 tensors",
+               "f32x3": "fp32-accurate, not the plain-fp32 instruction path of rounds 1-2's `f32` lines: the MFMA-bound GEMMs (1x1 convolutions "
+                        "with a long contraction, the fused MBConv expand GEMMs, the decoder's fc1 / vocabulary projection) as six exact bf16 "
+                        "products per multiply from three-way operand splits on the bf16 matrix cores, fp32 accumulate; every other kernel plain "
+                        "fp32; fp32 tensors; the plain-fp32 figure of the same step is in `plain_f32`",
+               "bf16": "bf16 products / f32 accumulate / f32 storage except the fused expand+depthwise results (bf16)"}
 
 TRAIN_WORKLOAD = ("transformer_word_level_bahdnau: teacher-forced training step (EfficientNet-B0 train mode + encoder block + "
                   "Bahdanau LSTMCell decoder, compute_loss, backward, AdamW)")
@@ -379,7 +443,7 @@ def train_parallelism(model, world):
     return f"data-parallel x{world}, bucketed all-reduce of {sum(p.numel() for p in model.parameters()) * 4 / 1e6:.1f} MB of gradients"
 
 
-def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256, dtype="f32"):
+def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256, dtype="f32", partial=None, cpu_base=False):
     note(rank, f"train secondary: building the model, batch {B}, {dtype}")
     """The second half of the metric, measured after the contract's timed region on the same ranks: K training steps
     between barriers, max over ranks -> the "train" object of the JSON line."""
@@ -397,7 +461,11 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256, dtype="f32
     torch.cuda.synchronize()
     ops.set_autotune(False)
     note(rank, "train secondary: first step (tuning) done")
-    check = verify_train(torch, ops, dev, rank, B, first_loss, 1000 + rank)      # every rank: the step contains the gradient exchange
+    tuned = {"loss1": first_loss, "grad_norm1": float(step.trainer.opt.flat.flat_g.double().norm().item())}
+    step()
+    tuned["loss3"] = float(step())
+    check = verify_train(torch, ops, dev, rank, B, tuned, 1000 + rank)      # every rank: the step contains the gradient exchange
+    note(rank, f"train secondary: verification {check}")
     DropoutState.manual_seed(2000 + rank)
     for _ in range(2):
         step()
@@ -412,10 +480,18 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256, dtype="f32
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    res = {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": 3,
-           "images_per_step_per_gpu": B, "dtype": TRAIN_DTYPES[dtype], "scaling": "weak", "loss_last_step": float(loss),
-           "workload": TRAIN_WORKLOAD, "parallelism": train_parallelism(model, world)}
+    red = step.trainer.reducer
+    res = {"value": world * B * steps / elapsed, "unit": "imgs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": 5,
+           "images_per_step_per_gpu": B, "dtype": dtype, "dtype_note": TRAIN_DTYPES[dtype], "scaling": "weak", "loss_last_step": float(loss),
+           "workload": TRAIN_WORKLOAD, "parallelism": train_parallelism(model, world),
+           "gradient_exchange": "none (single GPU)" if red is None else
+                                ("bucketed all-reduce launched by hooks during backward" if red.overlap else "bucketed all-reduce after backward")}
     res["verified"], res["verification"] = check["ok"], check                    # rank 0's own check is the one reported
+    # roofline of this step: every rank runs the traced step (it contains the gradient exchange), rank 0 reports it
+    res["roofline"] = traced_step_roofline(torch, ops, step, res["ms_per_step"])
+
+    if partial is not None:
+        partial.update(res)            # what a later stall must not lose
 
     def timed_as(kind, label):
         step.trainer.dtype = kind
@@ -435,10 +511,31 @@ def train_secondary(torch, dist, ops, dev, world, rank, steps, B=256, dtype="f32
         return {"value": world * B * steps / dt, "unit": "imgs/s", "ms_per_step": dt / steps * 1e3, "dtype": TRAIN_DTYPES[kind],
                 "loss_last_step": float(last)}
 
+    if red is not None and not red.overlap and not red.host_staged:
+        # RCCL: the default keeps the exchange after backward (launched from the calling thread); the hook-launched, overlapped
+        # form is measured next, after the figure above is safe - it has never run on multi-GPU hardware before this line
+        red.overlap = True
+        try:
+            ov = timed_as(dtype, "overlapped gradient exchange (hooks)")
+            ov["gradient_exchange"] = "bucketed all-reduce launched by hooks during backward"
+            ov["buckets_launched_by_hooks_last_step"] = red.hooked
+            res["overlapped"] = ov
+            if ov["value"] < res["value"]:
+                red.overlap = False        # the remaining variants run in the faster of the two forms
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            res["overlapped"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            red.overlap = False
+        if partial is not None:
+            partial.update(res)
     if dtype == "f32x3":        # the same trainer on the fp32 matrix-core instruction only, for comparison
         res["plain_f32"] = timed_as("f32", "plain fp32 products")
     # the same trainer with bf16 products (BASELINE configs[2] names bf16), same K steps between the same barriers
     res["bf16"] = dict(timed_as("bf16", "bf16 products"), tolerance=TRAIN_BF16_TOLERANCE)
+    if partial is not None:
+        partial.update(res)
+    if cpu_base and rank == 0:
+        res["cpu_baseline"] = cpu_train_baseline(torch, model, 12)
+        note(rank, "train secondary: CPU baseline measured")
     # single process only: the step at the reference's loader batch (12), replayed from a HIP graph (Trainer(graph=True))
     if world == 1:
         try:
@@ -645,6 +742,30 @@ def main():
                "unit": "captions/s", "ms_per_step": alt_elapsed / args.steps * 1e3,
                "tolerance": "features 1e-2, logits 2e-2 of their largest magnitude vs the f32 path (tests/test_gpu_bf16.py)"}
 
+    # the same step on the plain fp32 matrix-core instruction (the `f32` path of earlier rounds' lines), same K steps and barriers
+    plain = None
+    if not train and args.dtype == "f32x3" and not args.no_plain_f32:
+        ops.set_compute_dtype("f32")
+        ops.set_autotune(True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ops.set_autotune(False)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        pl_elapsed = time.perf_counter() - t1
+        ops.set_compute_dtype(args.dtype)
+        note(rank, f"plain-fp32 secondary: {args.steps} steps in {pl_elapsed:.2f} s")
+        if world > 1:
+            t = torch.tensor([pl_elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pl_elapsed = float(t.item())
+        plain = {"dtype": "f32", "dtype_note": DTYPE_NOTES["f32"], "value": world * B * args.steps / pl_elapsed, "unit": "captions/s",
+                 "ms_per_step": pl_elapsed / args.steps * 1e3}
+
     ops.set_compute_dtype("f32")      # everything after the timed region (single-caption decode, training) runs in its own modes
     out = None
     if rank == 0:
@@ -678,14 +799,18 @@ def main():
             "metric": "captions/sec greedy + train imgs/sec, 224px food imgs, 1/2/4/8 MI355X",
             "value": captions / elapsed, "unit": "imgs/s" if train else "captions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, **({"rehearsal": "gloo, shared devices: not a result"} if args.rehearse else {}), "dtype": TRAIN_DTYPES[args.dtype] if train else CAPTION_DTYPES[args.dtype] if args.dtype != "bf16" else "bf16 products / f32 accumulate / f32 storage except the fused expand+depthwise results (bf16)", "data": "synthetic",
+            "vs_baseline": None, **({"rehearsal": "gloo, shared devices: not a result"} if args.rehearse else {}), "dtype": TRAIN_DTYPES[args.dtype] if train else (CAPTION_DTYPES[args.dtype] if args.dtype != "bf16" else "bf16"),
+            "dtype_note": TRAIN_DTYPES[args.dtype] if train else DTYPE_NOTES[args.dtype], "data": "synthetic",
             "config": {"workload": workload, "images_per_step_per_gpu": B, "image": "3x224x224 fp32", "caption_tokens": CAPTION_LEN,
-                       "vocab": VOCAB, "weights": "seeded random init", "parallelism": par},
+                       "vocab": VOCAB, "weights": "seeded random init", "parallelism": par,
+                       "images": f"{min(B, 32)} unique seeded synthetic images tiled to the batch of {B} (distinct addresses: same HBM traffic as {B} different images)"},
             "roofline": roof,
         }
         if verified is not None:
             out["verified"] = verified["ok"]
             out["verification"] = verified
+        if plain is not None:
+            out["plain_f32"] = plain
         if alt is not None:
             out["bf16_mode"] = alt
         if not train and world == 1 and not args.no_decode_b1:
@@ -698,15 +823,18 @@ def main():
     # data-parallel path is measured wherever this line is.  It cannot take the line down with it: an exception becomes an
     # "error" entry, and a rank that does not come back within the deadline prints the line without it and exits.
     if not train and not args.no_train_mode:
+        partial = {}
+
         def emit_without():
             if rank == 0:
-                out["train"] = {"error": f"no result within {args.train_deadline:.0f} s"}
+                out["train"] = dict(partial, error=f"not finished within {args.train_deadline:.0f} s" + (" (the fields present were measured before the stall)" if partial else ""))
                 print(json.dumps(out), flush=True)
 
         def run():
             try:
                 return train_secondary(torch, dist, ops, dev, world, rank, max(1, min(args.steps, 10)), args.train_batch,
-                                       "f32x3" if args.dtype == "f32x3" else "f32")
+                                       "f32x3" if args.dtype == "f32x3" else "f32", partial=partial,
+                                       cpu_base=world == 1 and not args.no_cpu_baseline)
             except Exception as e:      # noqa: BLE001 - reported in the line (rank 0) and on stderr (every rank)
                 import traceback
                 note(rank, "train secondary failed: " + "".join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:])
@@ -768,34 +896,68 @@ def breakdown(torch, ops, step, B):
 
 
 def host_cpu_model():
+    """Model string and core counts of the host: /proc/cpuinfo's model name (with family / model / stepping numbers: some
+    hosts publish a shortened name), physical cores = distinct (physical id, core id) pairs, logical CPUs, and how many of
+    them this process may use."""
+    name, fam, mod, step, phys, cur_pkg = "unknown", "?", "?", "?", set(), None
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    name = v
+                elif k == "cpu family":
+                    fam = v
+                elif k == "model":
+                    mod = v
+                elif k == "stepping":
+                    step = v
+                elif k == "physical id":
+                    cur_pkg = v
+                elif k == "core id":
+                    phys.add((cur_pkg, v))
     except OSError:
         pass
-    return "unknown"
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 0
+    return {"model_name": name, "family_model_stepping": f"{fam}/{mod}/{step}", "physical_cores": len(phys) or None,
+            "logical_cpus": os.cpu_count(), "cpus_usable_by_this_process": usable}
 
 
 def cpu_baseline(torch, model, n):
     """The CPU oracle on the host cores over a bounded sample: n synthetic images -> EfficientNet-B0 features
     (once per image) -> 20 greedy steps per image with the reference's call pattern for the decoder (the model's
-    decoder side re-run on the growing prefix, one image at a time)."""
+    decoder side re-run on the growing prefix, one image at a time).  Run with torch's default thread count (the cores
+    this process may use) and, on a quarter of the sample, with 8 threads."""
     from image_captioning_amd.synthetic import synthetic_images
     from oracle import backbones_ref as BR, torch_ref as R
     sd = {k: (v.detach().cpu().float() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
-    imgs = synthetic_images(n, seed=99)
     threads = torch.get_num_threads()
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        feats = torch.cat([BR.cnn_model(sd, imgs[i:i + 16]) for i in range(0, n, 16)])
-        for f in feats:
-            R.tfm_greedy(sd, f, 8, 8, CAPTION_LEN, 2, 3, False)
-        dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "captions/s", "cores": threads, "kind": "port", "host_cpu": host_cpu_model(),
-            "sample": f"{n} synthetic 224x224 images: oracle EfficientNet-B0 (batches of 16) + per-image prefix-re-run greedy decode, "
-                      f"{CAPTION_LEN} tokens, fp32, torch CPU with {threads} threads, {dt:.1f} s"}
+
+    def run(count, seed):
+        imgs = synthetic_images(count, seed=seed)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            feats = torch.cat([BR.cnn_model(sd, imgs[i:i + 16]) for i in range(0, count, 16)])
+            for f in feats:
+                R.tfm_greedy(sd, f, 8, 8, CAPTION_LEN, 2, 3, False)
+            return time.perf_counter() - t0
+    dt = run(n, 99)
+    res = {"value": n / dt, "unit": "captions/s", "cores": threads, "kind": "port", "host_cpu": host_cpu_model(),
+           "sample": f"{n} synthetic 224x224 images: oracle EfficientNet-B0 (batches of 16) + per-image prefix-re-run greedy decode, "
+                     f"{CAPTION_LEN} tokens, fp32, torch CPU with {threads} threads, {dt:.1f} s"}
+    if threads != 8:
+        n8 = max(16, n // 4 // 16 * 16)
+        torch.set_num_threads(8)
+        try:
+            dt8 = run(n8, 98)
+        finally:
+            torch.set_num_threads(threads)
+        res["threads_8"] = {"value": n8 / dt8, "unit": "captions/s", "cores": 8, "sample": f"{n8} images, same pipeline, torch CPU with 8 threads, {dt8:.1f} s"}
+    return res
 
 
 def cpu_train_baseline(torch, model, B):
@@ -822,12 +984,14 @@ def cpu_train_baseline(torch, model, B):
         R.compute_loss(pred[:, :-1], caps[:, 1:], 0).backward()
         opt.step()
     one()
+    nsteps = 0
     t0 = time.perf_counter()
-    for _ in range(2):
+    while nsteps < 40 and (nsteps < 2 or time.perf_counter() - t0 < 10.0):      # a bounded sample: about 10 s of CPU work
         one()
-    dt = (time.perf_counter() - t0) / 2
+        nsteps += 1
+    dt = (time.perf_counter() - t0) / nsteps
     return {"value": B / dt, "unit": "imgs/s", "cores": threads, "kind": "port", "host_cpu": host_cpu_model(),
-            "sample": f"2 training steps of {B} synthetic images x {CAPTION_LEN} tokens (dropout masks omitted), oracle forward + torch "
+            "sample": f"{nsteps} training steps of {B} synthetic images x {CAPTION_LEN} tokens (dropout masks omitted), oracle forward + torch "
                       f"autograd + torch.optim.AdamW, fp32, torch CPU with {threads} threads, {dt:.1f} s per step"}
 
 

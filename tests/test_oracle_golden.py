@@ -77,6 +77,25 @@ def test_transformer(name, which):
     close(R.tfm_encoder(sd, feats[:3], eh), g["encoder_out_3"], "encoder")
 
 
+def test_word_transformer_at_the_test_script_widths():
+    """EMBED_DIM 512, FF_DIM 512, 8 / 8 heads, V = 6756, 10 tokens (TransformerTest.py:126,328-340): greedy ids, the batch-coupled
+    forward at the loader's 12 x 10 (a strided sample of the logits, every arg-max outside the gap rule) and the encoder block."""
+    g = H.load("word_tfm_testscript")
+    E, FF, eh, dh, V, start, end, steps = [int(v) for v in g["dims"]]
+    sd = H.cpu_sd(H.tfm_model("word", g["dims"], seed=int(g["seed"])))
+    feats = H.features(8, E, 104)
+    forced = [R.tfm_greedy(sd, feats[r], eh, dh, steps, start, end, False)[0] for r in range(3)]
+    H.assert_ids_match(np.array(forced), g["ids_forced"][:3], g["gaps"][:3], "word transformer, test-script widths")
+    caps = torch.from_numpy(g["fwd_caps_3x4"])
+    close(R.tfm_forward_features(sd, feats[:3], caps, eh, dh), g["fwd_logits_3x4"], "forward 3x4")
+    caps = torch.from_numpy(g["fwd_caps_12x10"])
+    logits = R.tfm_forward_features(sd, H.features(12, E, 105), caps, eh, dh)
+    close(logits[:, :, torch.from_numpy(g["fwd_logits_12x10_cols"])], g["fwd_logits_12x10"], "forward 12x10 (sampled columns)")
+    sure = g["fwd_gap_12x10"] >= H.GAP_EXEMPT
+    assert (logits.argmax(-1).numpy() == g["fwd_argmax_12x10"])[sure].all()
+    close(R.tfm_encoder(sd, feats[:3], eh), g["encoder_out_3"], "encoder")
+
+
 @pytest.mark.parametrize("tag", ["small", "full"])
 def test_bahdanau(tag):
     g = H.load(f"bahdanau_{tag}")

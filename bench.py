@@ -368,8 +368,23 @@ def decode_b1(torch, dev):
             for k in ("bytes_per_step", "achieved_gbs", "hbm_frac"):
                 del out[name][k]
             out[name]["us_per_step_equivalent"] = out[name].pop("us_per_step")
-    # bf16 weight streaming (icap_greedy_*_w16_f32): the weight matrices are read as bf16 copies, everything else stays fp32
+    # the same captions replayed from a whole-caption HIP graph (ops.set_decode_graph): launches inside a graph follow each
+    # other faster than stream-ordered ones; launches per step as in `mode`
     from image_captioning_amd import ops as _ops
+    launches = {"lstm": 3, "gru": 3, "word_transformer": 3, "bahdanau": 2}
+    _ops.set_decode_graph(True)
+    try:
+        for name, fn, steps in jobs[1:]:
+            ms = timeit(fn)
+            us = ms * 1e3 / steps
+            gbs = DECODE_PARAMS[name] * 4 / us / 1e3
+            out[name]["graph"] = {"us_per_step": us, "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                                  "us_per_dependent_launch": us / launches[name],
+                                  "note": "whole caption (every step's launches) replayed from one HIP graph; includes the copy into "
+                                          "the graph's input buffer and the copy of the ids out of it"}
+    finally:
+        _ops.set_decode_graph(False)
+    # bf16 weight streaming (icap_greedy_*_w16_f32): the weight matrices are read as bf16 copies, everything else stays fp32
     _ops.set_decode_weights("bf16")
     try:
         for name, fn, steps in jobs[1:]:

@@ -51,16 +51,20 @@ int expand_dwconv_img_x3_f32(const float* x, const void* we3p, const float* es, 
     nsplit = (nchunk + cpg - 1) / cpg;
     const long long wgs = groups * nsplit;
     if (wgs > 0x7fffffffLL) { set_error("expand_dwconv (whole image, split products): problem too large"); return ICAP_ERR_LIMIT; }
-    const dim3 grid((unsigned)wgs), block(256);
+    const dim3 grid((unsigned)wgs), block(256), block8(512);
     const uint4* wp = reinterpret_cast<const uint4*>(we3p);
 #define ICAP_X3(CIN_, KS_, HW_, NCB_) \
     hipLaunchKernelGGL((expand_dw_img_x3_kernel<CIN_, KS_, HW_, NCB_>), grid, block, 0, st, x, wp, es, eb, wd, ds, db, y, pooled, B, Cexp, nchunk, cpg, nsplit)
-    if (Cin == 80 && KS == 3) ICAP_X3(80, 3, 14, 2);
-    else if (Cin == 80) ICAP_X3(80, 5, 14, 2);
-    else if (Cin == 112 && KS == 3) ICAP_X3(112, 3, 14, 2);
-    else if (Cin == 112) ICAP_X3(112, 5, 14, 2);
+    // 14 x 14: eight waves, the A planes of the first five K slices in registers (all of them for 80 input channels)
+#define ICAP_X3W8(CIN_, KS_) \
+    hipLaunchKernelGGL((expand_dw_img14_w8_kernel<CIN_, KS_, 5>), grid, block8, 0, st, x, wp, es, eb, wd, ds, db, y, pooled, B, Cexp, nchunk, cpg, nsplit)
+    if (Cin == 80 && KS == 3) ICAP_X3W8(80, 3);
+    else if (Cin == 80) ICAP_X3W8(80, 5);
+    else if (Cin == 112 && KS == 3) ICAP_X3W8(112, 3);
+    else if (Cin == 112) ICAP_X3W8(112, 5);
     else if (KS == 3) ICAP_X3(192, 3, 7, 1);
     else ICAP_X3(192, 5, 7, 1);
+#undef ICAP_X3W8
 #undef ICAP_X3
     return launch_status("expand_dwconv (whole image, split products)");
 }

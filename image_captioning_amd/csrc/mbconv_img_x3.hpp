@@ -31,6 +31,13 @@ typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int X3_ROWS = 196;     // pixels per workgroup
 
+#ifdef X3_STAMP      // profiling probe: cycles wave 0 of each workgroup spends per phase, summed over workgroups
+__device__ unsigned long long x3_stamps[8];
+#define X3_T(i) do { if (tid == 0) { const long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; } } while (0)
+#else
+#define X3_T(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned x3_pk2(float a, float b) {       // (bf16(a), bf16(b)), a in the low half; round to nearest even
     const x3_f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, x3_bf16x2));
@@ -99,7 +106,12 @@ __global__ __launch_bounds__(256, 1) void expand_dw_img_x3_kernel(const float* _
     static_assert(HW == 14 || HW == 7, "whole-image tiles: 14 x 14 (one image) or 7 x 7 (four images)");
     static_assert(CIN % 16 == 0 && (KS == 3 || KS == 5) && (NCB == 1 || NCB == 2), "K slices of 16; 3x3 or 5x5; 32 or 64 channels per chunk");
     constexpr int IMGS = HW == 14 ? 1 : 4, PX = HW * HW, NK = CIN / 16, PAD = KS / 2, RPI = HW + 2 * PAD;
-    constexpr int XCH = 32 * NCB, ES = XCH + 4, NQ = XCH / 4, RSLOTS = 256 / NQ, NT = IMGS * HW;
+    constexpr int XCH = 32 * NCB, NQ = XCH / 4, RSLOTS = 256 / NQ, NT = IMGS * HW;
+    // E pixel pitch: for 64 channels exactly the 256 bytes of the LDS bank row, so the four-channel slices of ANY two pixels
+    // meet in a bank only for equal channels, and a 16-byte read's lane groups (which mix two depthwise tasks) never do;
+    // for 32 channels 36 floats
+    constexpr int ES = NCB == 2 ? XCH : XCH + 4;
+    constexpr int PD = 3;                                   // LDS reads of E a thread keeps in flight ahead of their use
     static_assert(NT <= RSLOTS, "one output row per thread");
     constexpr int WROWS = KS * KS + 2;                      // filter taps, folded-BN scale, folded-BN bias
     constexpr int NPW = (WROWS * NQ + 255) / 256;           // float4 parameter entries per thread
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void expand_dw_img_x3_kernel(const float* _
     // step 1 + cc takes input column cc: one LDS read feeding the outputs it touches); item KS is the epilogue (step 1 + c
     // finishes output column c; the last step stores the row and its channel sums).
     constexpr int STEPS = HW + 1;
-    float4 o[HW], wr[KS], evn, dsv, dbv, ps;
+    float4 o[HW], wr[KS], evq[PD], dsv, dbv, ps;
     auto dw_step = [&](int item, int step, int buf, int chunk) {
         if (item < KS) {
             const int dr = item;
@@ -230,14 +242,15 @@ __global__ __launch_bounds__(256, 1) void expand_dw_img_x3_kernel(const float* _
                 }
 #pragma unroll
                 for (int dc = 0; dc < KS; ++dc) wr[dc] = wds[buf][dr * KS + dc][q];
-                evn = *reinterpret_cast<const float4*>(&E[((timg * RPI + trow + dr) * HW) * ES + q * 4]);
+#pragma unroll
+                for (int d = 0; d < PD; ++d) evq[d] = *reinterpret_cast<const float4*>(&E[((timg * RPI + trow + dr) * HW + d) * ES + q * 4]);
                 return;
             }
-            // the value of this step was fetched by the step before, this one fetches the next: no step waits for the
-            // read it has just issued
+            // the value of this step was fetched PD steps ago, this step fetches the one PD steps ahead: an LDS read under
+            // load takes longer than one step's twenty FMAs
             const int cc = step - 1;
-            const float4 ev = evn;
-            if (cc + 1 < HW) evn = *reinterpret_cast<const float4*>(&E[((timg * RPI + trow + dr) * HW + cc + 1) * ES + q * 4]);
+            const float4 ev = evq[cc % PD];
+            if (cc + PD < HW) evq[cc % PD] = *reinterpret_cast<const float4*>(&E[((timg * RPI + trow + dr) * HW + cc + PD) * ES + q * 4]);
 #pragma unroll
             for (int dc = 0; dc < KS; ++dc) {
                 const int c = cc - dc + PAD;
@@ -379,6 +392,320 @@ __global__ __launch_bounds__(256, 1) void expand_dw_img_x3_kernel(const float* _
         x3_lds_barrier();
         pooled_reduce(c);
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The 14 x 14 layers with EIGHT waves (two per SIMD).  One wave per SIMD issues a vector instruction every four cycles at
+// best and has nobody to cover its stalls; two waves issue one every two cycles between them and cover each other.  With
+// 256 registers per wave the stationary A planes of TWO row blocks no longer fit, so a wave owns ONE 32-pixel row block
+// (wave 7's block is empty: it only joins the barriers) and keeps the planes of the first NKR K slices in registers, the
+// rest in LDS (written once, read back by the same wave).  The depthwise tasks are HALF rows (7 outputs): a thread of the
+// right half works on the mirrored row - column 13 - u, tap KS - 1 - j - so both halves run the same instruction stream.
+template <int CIN, int KS, int NKR>
+__global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float* __restrict__ x, const uint4* __restrict__ we3p,
+                                                                    const float* __restrict__ es, const float* __restrict__ eb,
+                                                                    const float* __restrict__ wd, const float* __restrict__ ds,
+                                                                    const float* __restrict__ db, float* __restrict__ y,
+                                                                    float* __restrict__ pooled, int B, int Cexp, int nchunk, int cpg,
+                                                                    int nsplit) {
+    constexpr int HW = 14, PX = HW * HW, NK = CIN / 16, PAD = KS / 2, RPI = HW + 2 * PAD, NCB = 2;
+    constexpr int XCH = 64, ES = XCH, NQ = 16, HALF = 7, NT = 2 * HW, NIN = HALF + PAD;     // ES: see the four-wave kernel
+    constexpr int PD = 2;                                   // LDS reads of E in flight ahead of their use
+    constexpr int NKL = NK > NKR ? NK - NKR : 0;            // K slices whose A planes live in LDS
+    constexpr int WROWS = KS * KS + 2;
+    static_assert(WROWS * NQ <= 512, "one float4 parameter entry per thread");
+    constexpr int E_FLOATS = RPI * HW * ES;
+    constexpr int NITEMS = KS + 1;
+    __shared__ __attribute__((aligned(16))) float E[E_FLOATS];
+    __shared__ float4 wds[2][WROWS][NQ];
+    __shared__ __attribute__((aligned(16))) float red[NT][XCH];
+    __shared__ uint4 Al[NKL ? NKL : 1][3][2][256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    const int t_lin = xcd * (nwg >> 3) + (xcd < (nwg & 7) ? xcd : (nwg & 7)) + slot0;
+    const int img0 = t_lin / nsplit, split = t_lin - img0 * nsplit;
+    const int c0 = split * cpg, c1 = min(nchunk, c0 + cpg);
+    if (c0 >= c1) return;
+#ifdef X3_STAMP
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
+    const bool img_ok = img0 < B;
+    const bool works = wave < 7;                            // wave-uniform: row block 7 holds no pixel, slots 28..31 no task
+
+    // depthwise task: output row trow, half th (0: columns 0..6, 1: columns 13..7 in that order), four channels
+    const int q = tid % NQ, slot = tid / NQ;
+    const bool tvalid = slot < NT;
+    const int task = tvalid ? slot : 0;
+    const int th = task / HW, trow = task - th * HW;        // a wave's four tasks: consecutive rows of one half
+
+    for (int idx = tid; idx < E_FLOATS / 4; idx += 512) reinterpret_cast<float4*>(E)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 pw;
+    auto load_dw_params = [&](int chunk) {
+        const int row = tid / NQ, qq = tid - row * NQ;
+        const int c = chunk * XCH + qq * 4;
+        const bool ok = row < WROWS && c < Cexp;
+        const float* src = row < KS * KS ? wd + (size_t)row * Cexp : (row == KS * KS ? ds : db);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row == KS * KS && !ds) v = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (ok && src) v = *reinterpret_cast<const float4*>(src + c);
+        pw = v;
+    };
+    auto store_dw_params = [&](int buf) {
+        if (tid < WROWS * NQ) (&wds[buf][0][0])[tid] = pw;
+    };
+    float esc[NCB], ebc[NCB];
+    auto load_expand_params = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            const int c = chunk * XCH + 32 * j + lr;
+            const bool ok = c < Cexp;
+            esc[j] = (ok && es) ? es[c] : 1.f;
+            ebc[j] = (ok && eb) ? eb[c] : 0.f;
+        }
+    };
+
+    // ---- A: row wave * 32 + lr, this lane's half of every K slice, split once
+    uint4 a16[NKR < NK ? NKR : NK][3];
+    {
+        const int row = wave * 32 + lr;
+        const bool ok = row < X3_ROWS && img_ok;
+        const float* src = x + ((size_t)(img_ok ? img0 : 0) * PX + (ok ? row : 0)) * CIN + 8 * lh;
+#pragma unroll
+        for (int t = 0; t < NK; ++t) {
+            const float4 v0 = *reinterpret_cast<const float4*>(src + 16 * t), v1 = *reinterpret_cast<const float4*>(src + 16 * t + 4);
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            uint4 pl[3];
+            x3_split8(f, ok, pl[0], pl[1], pl[2]);
+            if (t < NKR) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a16[t][p] = pl[p];
+                    // anchored in ordinary registers: with two waves per SIMD the compiler splits the 256 registers evenly
+                    // between the two classes as soon as one value asks for the accumulator class, and 128 are too few here
+                    asm volatile("" : "+v"(a16[t][p].x), "+v"(a16[t][p].y), "+v"(a16[t][p].z), "+v"(a16[t][p].w));
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) Al[t - NKR][p][lh][wave * 32 + lr] = pl[p];     // read back by this wave only
+            }
+        }
+    }
+
+    auto load_b = [&](int chunk, int t, uint4 (&bf)[NCB][3]) {
+        const uint4* src = we3p + ((size_t)(chunk * NK + t) * 6 + lh) * XCH + lr;
+#pragma unroll
+        for (int j = 0; j < NCB; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = src[p * 2 * XCH + 32 * j];
+    };
+    // A planes of slice t for the matrix instructions: the registers, or this wave's rows of the LDS copy
+    auto load_a = [&](int t, uint4 (&af)[3]) {
+        if (t >= NKR) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = Al[t - NKR][p][lh][wave * 32 + lr];
+        }
+    };
+
+    x3_f32x16 acc[NCB];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < NCB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    };
+    constexpr int NM = 6 * NCB;                             // matrix instructions per K slice and wave
+    auto mfma_one = [&](int t, int m, const uint4 (&af)[3], const uint4 (&bf)[NCB][3]) {
+        constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+        const int j = m % NCB, pr = m / NCB;
+        const uint4 a = t < NKR ? a16[t < NKR ? t : 0][pa[pr]] : af[pa[pr]];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3_bf16x8, a), __builtin_bit_cast(x3_bf16x8, bf[j][pb[pr]]),
+                                                         acc[j], 0, 0, 0);
+        asm volatile("" : "+v"(acc[j]));
+    };
+
+    // ---- depthwise steps (see the four-wave kernel): item k < KS = filter row k (step 0: taps; step 1 + u: input u of the
+    // mirrored half row), item KS = epilogue (step 1 + l: output l; the last step stores)
+    constexpr int ROW_STEPS = NIN + 1, EPI_STEPS = HALF + 1;
+    float4 o[HALF], wr[KS], evq[PD], dsv, dbv, ps;
+    auto ecol = [&](int u) { return th ? HW - 1 - u : u; };
+    auto dw_step = [&](int item, int step, int buf, int chunk) {
+        if (item < KS) {
+            const int dr = item;
+            const float* erow = &E[((trow + dr) * HW) * ES + q * 4];
+            if (step == 0) {
+                if (dr == 0) {
+#pragma unroll
+                    for (int l = 0; l < HALF; ++l) o[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < KS; ++j) wr[j] = wds[buf][dr * KS + (th ? KS - 1 - j : j)][q];
+#pragma unroll
+                for (int d = 0; d < PD; ++d) evq[d] = *reinterpret_cast<const float4*>(erow + ecol(d) * ES);
+                return;
+            }
+            const int u = step - 1;
+            const float4 ev = evq[u % PD];
+            if (u + PD < NIN) evq[u % PD] = *reinterpret_cast<const float4*>(erow + ecol(u + PD) * ES);
+#pragma unroll
+            for (int l = 0; l < HALF; ++l) {
+                const int j = u - l + PAD;                   // mirrored tap feeding output l from input u
+                if (j >= 0 && j < KS) {
+                    o[l].x = fmaf(ev.x, wr[j].x, o[l].x);
+                    o[l].y = fmaf(ev.y, wr[j].y, o[l].y);
+                    o[l].z = fmaf(ev.z, wr[j].z, o[l].z);
+                    o[l].w = fmaf(ev.w, wr[j].w, o[l].w);
+                    asm volatile("" : "+v"(o[l].x), "+v"(o[l].y), "+v"(o[l].z), "+v"(o[l].w));
+                }
+            }
+        } else {
+            if (step == 0) {
+                dsv = wds[buf][KS * KS][q];
+                dbv = wds[buf][KS * KS + 1][q];
+                ps = make_float4(0.f, 0.f, 0.f, 0.f);
+                return;
+            }
+            const int l = step - 1;
+            float4 v;
+            v.x = fmaf(o[l].x, dsv.x, dbv.x); v.y = fmaf(o[l].y, dsv.y, dbv.y); v.z = fmaf(o[l].z, dsv.z, dbv.z); v.w = fmaf(o[l].w, dsv.w, dbv.w);
+            v.x *= sigmoid_fast(v.x); v.y *= sigmoid_fast(v.y); v.z *= sigmoid_fast(v.z); v.w *= sigmoid_fast(v.w);
+            o[l] = v;
+            ps.x += v.x; ps.y += v.y; ps.z += v.z; ps.w += v.w;
+            asm volatile("" : "+v"(o[l].x), "+v"(o[l].y), "+v"(o[l].z), "+v"(o[l].w), "+v"(ps.x), "+v"(ps.y), "+v"(ps.z), "+v"(ps.w));
+            if (step == HALF) {
+                const int cb = chunk * XCH + q * 4;
+                const bool st_ok = tvalid && img_ok && cb < Cexp;
+                float* dst = y + (((size_t)(img_ok ? img0 : 0) * PX + trow * HW) * Cexp + (cb < Cexp ? cb : 0));
+                if (st_ok) {
+#pragma unroll
+                    for (int l2 = 0; l2 < HALF; ++l2) *reinterpret_cast<float4*>(dst + (size_t)ecol(l2) * Cexp) = o[l2];
+                }
+                if (tvalid) *reinterpret_cast<float4*>(&red[task][q * 4]) = ps;
+            }
+        }
+    };
+    auto item_steps = [](int item) { return item < KS ? ROW_STEPS : EPI_STEPS; };
+
+    auto pooled_reduce = [&](int chunk) {
+        if (!pooled || tid >= XCH) return;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < HW; ++r) s += red[r][tid] + red[HW + r][tid];      // rows in order, left half + right half
+        const int cg = chunk * XCH + tid;
+        if (cg < Cexp && img_ok) pooled[(size_t)img0 * Cexp + cg] = s;
+    };
+    auto e_write = [&]() {
+        const int rb = wave;
+        if (rb * 32 < X3_ROWS) {
+            const bool full = rb * 32 + 32 <= X3_ROWS;
+#pragma unroll
+            for (int j = 0; j < NCB; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float v = fmaf(acc[j][e], esc[j], ebc[j]);
+                    if (full) E[(row + PAD * HW) * ES + 32 * j + lr] = v * sigmoid_fast(v);
+                    else if (e < 4 && lh == 0) E[(row + PAD * HW) * ES + 32 * j + lr] = v * sigmoid_fast(v);
+                }
+        }
+        zero_acc();
+    };
+
+    // ---- first chunk: GEMM alone
+    uint4 bcur[NCB][3], bnxt[NCB][3], acur[3], anxt[3];
+    X3_T(0);                 // prologue: E zero, A load + split
+    load_dw_params(c0);
+    load_expand_params(c0);
+    zero_acc();
+    if (works) {
+        load_b(c0, 0, bcur);
+        load_a(0, acur);
+        x3_static_for<NK>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if (t + 1 < NK) load_b(c0, t + 1, bnxt);
+            else load_b(min(c0 + 1, c1 - 1), 0, bnxt);
+            load_a((t + 1) % NK, anxt);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) mfma_one(t, m, acur, bcur);
+#pragma unroll
+            for (int j = 0; j < NCB; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bcur[j][p] = bnxt[j][p];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) acur[p] = anxt[p];
+        });
+    }
+    X3_T(1);                 // first GEMM
+    x3_lds_barrier();
+    store_dw_params(0);
+    e_write();
+    x3_lds_barrier();
+    X3_T(2);                 // first E write + barriers
+
+    for (int c = c0; c + 1 < c1; ++c) {
+        const int buf = (c - c0) & 1;
+        load_dw_params(c + 1);
+        load_expand_params(c + 1);
+        if (works) {
+            x3_static_for<NK>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if (t + 1 < NK) load_b(c + 1, t + 1, bnxt);
+                else load_b(min(c + 2, c1 - 1), 0, bnxt);
+                load_a((t + 1) % NK, anxt);
+                constexpr int k0 = (t * NITEMS + NK - 1) / NK, k1 = ((t + 1) * NITEMS + NK - 1) / NK;
+                // steps of the items [k0, k1) that run beside this slice, in order: (item, step) pairs numbered g = 0 .. S - 1
+                constexpr int S = (k1 > k0 ? (k1 - k0 - (k1 == NITEMS ? 1 : 0)) * ROW_STEPS + (k1 == NITEMS ? EPI_STEPS : 0) : 0);
+                x3_static_for<NM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    mfma_one(t, m, acur, bcur);
+                    if constexpr (S > 0) {
+                        x3_static_for<S>([&](auto gc) {
+                            constexpr int g = decltype(gc)::value;
+                            if constexpr (g * NM / S == m) {
+                                constexpr int item = k0 + g / ROW_STEPS;        // only the chunk's last item is shorter
+                                dw_step(item, g - (item - k0) * ROW_STEPS, buf, c);
+                            }
+                        });
+                    }
+                });
+#pragma unroll
+                for (int j = 0; j < NCB; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bcur[j][p] = bnxt[j][p];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) acur[p] = anxt[p];
+            });
+        }
+        X3_T(3);             // steady slices
+        x3_lds_barrier();
+        X3_T(4);             // barrier after the slices
+        pooled_reduce(c);
+        store_dw_params(buf ^ 1);
+        e_write();
+        X3_T(5);             // pooled + E write
+        x3_lds_barrier();
+        X3_T(6);             // barrier after the E write
+    }
+
+    {
+        const int c = c1 - 1, buf = (c - c0) & 1;
+        if (works) {
+#pragma unroll
+            for (int k = 0; k < NITEMS; ++k)
+#pragma unroll
+                for (int st = 0; st < (k < KS ? ROW_STEPS : EPI_STEPS); ++st) dw_step(k, st, buf, c);
+        }
+        x3_lds_barrier();
+        pooled_reduce(c);
+    }
+    X3_T(7);                 // drain
+#ifdef X3_STAMP
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&x3_stamps[i], (unsigned long long)st_acc[i]);
+#endif
 }
 
 }  // namespace icap

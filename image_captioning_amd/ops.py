@@ -1014,6 +1014,53 @@ def _w16(wd: dict, key: str, idx=None) -> int:
     return t.data_ptr()
 
 
+# Whole-caption HIP graphs for the lock-step greedy drivers (opt-in).  icap_greedy_* enqueue every launch of a caption
+# without a host round trip, so the launches of one call can be recorded once and replayed: a replay costs one graph launch
+# on the host, and dependent kernels inside a graph follow each other faster than stream-ordered launches do.  The recorded
+# graph reads its inputs from static buffers (a call copies into them) and writes ids / logits / workspace owned by the
+# graph's memory pool; results are returned as copies.  Graphs live inside the prepared-weights dict `wd`, which is rebuilt
+# whenever the weights change, so a graph never outlives the weight copies it points to.
+DECODE_GRAPH = False
+_DECODE_GRAPH_MAX = 8        # graphs kept per prepared-weights dict (distinct batch sizes / step counts)
+
+
+def set_decode_graph(flag: bool) -> None:
+    global DECODE_GRAPH
+    DECODE_GRAPH = bool(flag)
+
+
+def _graphed_caption(wd: dict, key, inputs, run):
+    """run(inputs) -> tuple of tensors / None, either directly or - with DECODE_GRAPH on - as a replay of the HIP graph
+    recorded for (wd, key) on static copies of `inputs`."""
+    if not DECODE_GRAPH or torch.cuda.is_current_stream_capturing():
+        return run(inputs)
+    cache = wd.setdefault("_caption_graphs", {})
+    ent = cache.get(key)
+    if ent is None:
+        static = [t.clone() for t in inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # first run outside the recording: lazy weight copies are made here
+            run(static)
+        torch.cuda.current_stream().wait_stream(side)
+        tune = AUTOTUNE
+        set_autotune(False)                      # tuning synchronises; a recording must not
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = run(static)
+        finally:
+            set_autotune(tune)
+        if len(cache) >= _DECODE_GRAPH_MAX:
+            cache.pop(next(iter(cache)))
+        ent = cache[key] = (graph, static, outs)
+    graph, static, outs = ent
+    for st, t in zip(static, inputs):
+        st.copy_(t)
+    graph.replay()
+    return tuple(o.clone() if o is not None else None for o in outs)
+
+
 def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, ids=None, logits=None, static_ws=False, w16=None):
     """wd: dict with is_lstm, w_ih/w_hh/b_ih/b_hh lists, fc_w, fc_b, in_table.  x0 [NB, I].
     static_ws: the entry point whose workspace lives inside the library (nothing is allocated when `ids` - and `logits`
@@ -1036,6 +1083,7 @@ def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, ids=No
     w.fc_w = _w16(wd, "fc_w") if w16 else _ck(wd["fc_w"], "fc_w")
     w.fc_b, w.in_table = _ck(wd["fc_b"], "fc_b"), _ck(wd["in_table"], "in_table")
     dev = x0.device
+    user_buffers = ids is not None or logits is not None
     if ids is None:
         ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
     elif tuple(ids.shape) != (NB, steps):
@@ -1048,11 +1096,22 @@ def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, ids=No
         N.check(lib.icap_greedy_rnn_static_f32(C.byref(w), _ck(x0, "x0"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"),
                                                NB, steps, _stream()), "greedy_rnn_static")
         return ids, logits
-    ws = torch.empty(lib.icap_greedy_rnn_ws_floats(NB, L, H, I, V), device=dev, dtype=torch.float32)
     fn = lib.icap_greedy_rnn_w16_f32 if w16 else lib.icap_greedy_rnn_f32
-    N.check(fn(C.byref(w), _ck(x0, "x0"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()),
-            "greedy_rnn")
-    return ids, logits
+    ws_floats = lib.icap_greedy_rnn_ws_floats(NB, L, H, I, V)
+    if user_buffers or not DECODE_GRAPH:
+        ws = torch.empty(ws_floats, device=dev, dtype=torch.float32)
+        N.check(fn(C.byref(w), _ck(x0, "x0"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()),
+                "greedy_rnn")
+        return ids, logits
+
+    def run(inp):        # buffers allocated here: inside the recording they belong to the graph's pool
+        i = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+        lg = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+        ws = torch.empty(ws_floats, device=dev, dtype=torch.float32)
+        N.check(fn(C.byref(w), _ck(inp[0], "x0"), _ck(i, "ids", torch.int64), _ck(lg, "logits"), _ck(ws, "ws"), NB, steps, _stream()),
+                "greedy_rnn")
+        return i, lg
+    return _graphed_caption(wd, ("rnn", NB, I, steps, bool(want_logits), bool(w16)), (x0,), run)
 
 
 def greedy_tfm(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False, w16=None):
@@ -1067,13 +1126,17 @@ def greedy_tfm(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, steps: int, 
     for k in ("emb", "ln2_g", "ln2_b", "ln3_g", "ln3_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "out_w", "out_b"):
         setattr(w, k, _w16(wd, k) if w16 and k in ("fc1_w", "fc2_w", "out_w") else _ck(wd[k], k))
     dev = ca.device
-    ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
-    logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
-    ws = torch.empty(lib.icap_greedy_tfm_ws_floats(NB, E, FF, V), device=dev, dtype=torch.float32)
     fn = lib.icap_greedy_tfm_w16_f32 if w16 else lib.icap_greedy_tfm_f32
-    N.check(fn(C.byref(w), _ck(ca, "ca"), _ck(start_ids, "start_ids", torch.int64), _ck(ids, "ids", torch.int64),
-               _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()), "greedy_tfm")
-    return ids, logits
+    ws_floats = lib.icap_greedy_tfm_ws_floats(NB, E, FF, V)
+
+    def run(inp):
+        ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+        logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+        ws = torch.empty(ws_floats, device=dev, dtype=torch.float32)
+        N.check(fn(C.byref(w), _ck(inp[0], "ca"), _ck(inp[1], "start_ids", torch.int64), _ck(ids, "ids", torch.int64),
+                   _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()), "greedy_tfm")
+        return ids, logits
+    return _graphed_caption(wd, ("tfm", NB, steps, bool(want_logits), bool(w16)), (ca, start_ids), run)
 
 
 def table_walk(nxt, start, steps, logits_tab=None, V=None):
@@ -1133,10 +1196,14 @@ def greedy_bah(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, steps: 
     for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "fc_w", "fc_scale", "fc_bias"):
         setattr(w, k, _w16(wd, k) if w16 and k in ("w_ih", "w_hh", "fc_w") else _ck(wd[k], k))
     dev = context.device
-    ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
-    logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
-    ws = torch.empty(lib.icap_greedy_bah_ws_floats(NB, E, ENC, H, V), device=dev, dtype=torch.float32)
     fn = lib.icap_greedy_bah_w16_f32 if w16 else lib.icap_greedy_bah_f32
-    N.check(fn(C.byref(w), _ck(context, "context"), ENC, _ck(start_ids, "start_ids", torch.int64), _ck(ids, "ids", torch.int64),
-               _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()), "greedy_bah")
-    return ids, logits
+    ws_floats = lib.icap_greedy_bah_ws_floats(NB, E, ENC, H, V)
+
+    def run(inp):
+        ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+        logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+        ws = torch.empty(ws_floats, device=dev, dtype=torch.float32)
+        N.check(fn(C.byref(w), _ck(inp[0], "context"), ENC, _ck(inp[1], "start_ids", torch.int64), _ck(ids, "ids", torch.int64),
+                   _ck(logits, "logits"), _ck(ws, "ws"), NB, steps, _stream()), "greedy_bah")
+        return ids, logits
+    return _graphed_caption(wd, ("bah", NB, ENC, steps, bool(want_logits), bool(w16)), (context, start_ids), run)

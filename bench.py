@@ -355,7 +355,9 @@ def decode_b1(torch, dev):
     bm = seeded(bah.ImageCaptioningModel(Pass(), bah.TransformerEncoderBlock(512, 512, 8, dropout=0.5), bah.BahdanauDecoder(512, 512, 512, 256, VOCAB, dropout=0.5)), 31)
     jobs.append(("bahdanau", lambda: bm.greedy_ids_from_features(f512, CAPTION_LEN), CAPTION_LEN))
     modes = {"char_transformer": "next-token table: one batched decoder pass over 81 rows, then 58 look-ups (the decoder has no self-attention or positional encoding, so logits depend on the last token and the image only)",
-             "lstm": "3 launches per step", "gru": "3 launches per step", "word_transformer": "3 launches per step", "bahdanau": "2 launches per step"}
+             "lstm": "2 launches per step (layer 0's cell in the prologue of layer 1's input rows; layer 1's cell in the prologue of the vocabulary projection, which also carries both layers' recurrent rows for the next step)",
+             "gru": "2 launches per step (as lstm)", "word_transformer": "3 launches per step",
+             "bahdanau": "1 launch per step (cell in the prologue; vocabulary projection + recurrent rows for the next step)"}
     for name, fn, steps in jobs:
         ms = timeit(fn)
         us = ms * 1e3 / steps
@@ -371,7 +373,28 @@ def decode_b1(torch, dev):
     # the same captions replayed from a whole-caption HIP graph (ops.set_decode_graph): launches inside a graph follow each
     # other faster than stream-ordered ones; launches per step as in `mode`
     from image_captioning_amd import ops as _ops
-    launches = {"lstm": 3, "gru": 3, "word_transformer": 3, "bahdanau": 2}
+    launches = {"lstm": 2, "gru": 2, "word_transformer": 3, "bahdanau": 1}
+    # the recurrent decoders with one launch per cell (three per step for the two-layer LSTM / GRU, two for the LSTMCell decoder)
+    _ops.set_decode_fused(False)
+    try:
+        for name, fn, steps in jobs[1:]:
+            if name == "word_transformer":
+                continue
+            ms = timeit(fn)
+            us = ms * 1e3 / steps
+            gbs = DECODE_PARAMS[name] * 4 / us / 1e3
+            out[name]["launch_per_cell"] = {"us_per_step": us, "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                                            "launches_per_step": launches[name] + 1}
+    finally:
+        _ops.set_decode_fused(True)
+    # what the fused forms actually stream per step: W_ih of the token-fed cell has become a table row (4 H floats per step)
+    streamed = {"lstm": DECODE_PARAMS["lstm"] - 4 * 512 * 512, "gru": DECODE_PARAMS["gru"] - 3 * 512 * 512,
+                "bahdanau": 512 * VOCAB + 4 * 512 * 512 + 2 * VOCAB}
+    for name in launches:
+        out[name]["us_per_dependent_launch"] = out[name]["us_per_step"] / launches[name]
+        if name in streamed:
+            out[name]["streamed_bytes_per_step"] = streamed[name] * 4
+            out[name]["hbm_frac_streamed"] = streamed[name] * 4 / out[name]["us_per_step"] / 1e3 / HBM_PEAK_GBS
     _ops.set_decode_graph(True)
     try:
         for name, fn, steps in jobs[1:]:

@@ -119,6 +119,10 @@ SIGNATURES = {
     "icap_greedy_tfm_w16_f32": (_i, [C.POINTER(TfmWeights), _p, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_bah_w16_f32": (_i, [C.POINTER(BahWeights), _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_bah_ws_floats": (_ll, [_i] * 5),
+    "icap_greedy_bah_fused_ws_floats": (_ll, [_i] * 3),
+    "icap_greedy_bah_fused_f32": (_i, [_p] * 10 + [_i] * 4 + [_p]),
+    "icap_greedy_rnn2_fused_ws_floats": (_ll, [_i] * 4),
+    "icap_greedy_rnn2_fused_f32": (_i, [_i] + [_p] * 13 + [_i] * 4 + [_p]),
     "icap_ce_loss_fwd_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _ll, _i, _p, _p, _p, _p]),
     "icap_ce_loss_bwd_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _ll, _p, _p, _p, _p, _i, _p]),
     "icap_adamw_f32": (_i, [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _f, _p]),

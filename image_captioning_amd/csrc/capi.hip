@@ -26,6 +26,12 @@ int conv_igemm_tune_f32(const float*, const float*, const float*, const float*, 
 int conv_igemm_tuned_cfg(int, int, int, int, int, int, int, int, int, int);
 int conv_igemm_num_cfgs();
 int table_walk(const long long*, const long long*, long long*, const float*, int, float*, int, int, int, hipStream_t);
+long long greedy_bah_fused_ws_floats(int, int, int);
+int greedy_bah_fused_f32(const float*, const float*, const float*, const float*, const float*, const float*, const long long*, long long*,
+                         float*, float*, int, int, int, int, hipStream_t);
+long long greedy_rnn2_fused_ws_floats(int, int, int, int);
+int greedy_rnn2_fused_f32(int, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                          const float*, const float*, const float*, long long*, float*, float*, int, int, int, int, hipStream_t);
 int greedy_tfm_persist_max_nb(int, int, int);
 long long greedy_tfm_persist_ws_bytes(int, int, int, int);
 int greedy_tfm_persist_f32(const icap_tfm_weights*, const float*, const long long*, long long*, float*, void*, int, int, hipStream_t);
@@ -669,6 +675,26 @@ int icap_greedy_bah_f32(const icap_bah_weights* w, const float* context, int ENC
 int icap_greedy_bah_w16_f32(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
                             long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream) {
     return greedy_bah_impl(w, context, ENC, start_ids, ids, logits_out, ws, NB, steps, stream, true);
+}
+
+// ------------------------------------------------------------------ greedy: fewer dependent launches per step (decode_fused.hip)
+long long icap_greedy_bah_fused_ws_floats(int NB, int H, int V) { return greedy_bah_fused_ws_floats(NB, H, V); }
+
+int icap_greedy_bah_fused_f32(const float* g_tab, const float* g_ctx, const float* w_hh, const float* fc_w, const float* fc_scale,
+                              const float* fc_bias, const long long* start_ids, long long* ids, float* logits_out, float* ws,
+                              int NB, int H, int V, int steps, void* stream) {
+    return greedy_bah_fused_f32(g_tab, g_ctx, w_hh, fc_w, fc_scale, fc_bias, start_ids, ids, logits_out, ws, NB, H, V, steps,
+                                (hipStream_t)stream);
+}
+
+long long icap_greedy_rnn2_fused_ws_floats(int NB, int is_lstm, int H, int V) { return greedy_rnn2_fused_ws_floats(NB, is_lstm ? 4 : 3, H, V); }
+
+int icap_greedy_rnn2_fused_f32(int is_lstm, const float* g_tab0, const float* g_first, const float* w_hh0, const float* hh0_bias,
+                               const float* w_ih1, const float* ih1_bias, const float* w_hh1, const float* hh1_bias,
+                               const float* fc_w, const float* fc_b, long long* ids, float* logits_out, float* ws, int NB, int H,
+                               int V, int steps, void* stream) {
+    return greedy_rnn2_fused_f32(is_lstm, g_tab0, g_first, w_hh0, hh0_bias, w_ih1, ih1_bias, w_hh1, hh1_bias, fc_w, fc_b, ids,
+                                 logits_out, ws, NB, H, V, steps, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ training step

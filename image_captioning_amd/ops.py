@@ -1061,16 +1061,84 @@ def _graphed_caption(wd: dict, key, inputs, run):
     return tuple(o.clone() if o is not None else None for o in outs)
 
 
+# Latency form of the recurrent greedy drivers (icap_greedy_bah_fused_f32 / icap_greedy_rnn2_fused_f32): the token-dependent
+# input side of a cell is a row of a [V, G H] table made once per weight version, the recurrent side is computed a step ahead
+# by the vocabulary-projection launch, and the cell update is redone in every workgroup's prologue - one launch per step for
+# the Bahdanau LSTMCell decoder, two for the two-layer LSTM / GRU.  Every workgroup repeats the prologue, so the form pays
+# only while few captions are in flight: it is taken for at most DECODE_FUSED_MAX_NB captions per call, fp32 weights.
+DECODE_FUSED = True
+DECODE_FUSED_MAX_NB = 2
+
+
+def set_decode_fused(flag: bool) -> None:
+    global DECODE_FUSED
+    DECODE_FUSED = bool(flag)
+
+
+def _rnn2_fused_tables(wd: dict) -> dict:
+    """Prepared operands of icap_greedy_rnn2_fused_f32, kept in wd (rebuilt with the weights)."""
+    t = wd.get("_fused")
+    if t is None:
+        lstm = wd["is_lstm"]
+        in_bias0 = wd["b_ih"][0] + wd["b_hh"][0] if lstm else wd["b_ih"][0]
+        t = wd["_fused"] = {
+            "in_bias0": in_bias0.contiguous(),
+            "g_tab0": linear(wd["in_table"], wd["w_ih"][0], bias=in_bias0),
+            "ih1_bias": (wd["b_ih"][1] + wd["b_hh"][1]).contiguous() if lstm else wd["b_ih"][1],
+            "hh0_bias": None if lstm else wd["b_hh"][0],
+            "hh1_bias": None if lstm else wd["b_hh"][1],
+        }
+    return t
+
+
+def greedy_rnn2_fused(wd: dict, x0: torch.Tensor, steps: int, want_logits=False):
+    """greedy_rnn for a two-layer LSTM / GRU whose layers are all H wide, two launches per step
+    (icap_greedy_rnn2_fused_f32).  x0 [NB, H]: feature_fc of the image feature, the first step's input."""
+    lib = N.load()
+    NB, I = x0.shape
+    H = wd["w_hh"][0].shape[1]
+    V = wd["fc_w"].shape[0]
+    if len(wd["w_ih"]) != 2 or I != H or wd["w_ih"][1].shape[1] != H:
+        raise IcapError("greedy_rnn2_fused: needs two layers of one width")
+    t = _rnn2_fused_tables(wd)
+    lstm = int(wd["is_lstm"])
+    dev = x0.device
+    ws_floats = lib.icap_greedy_rnn2_fused_ws_floats(NB, lstm, H, V)
+
+    def run(inp):
+        g_first = linear(inp[0], wd["w_ih"][0], bias=t["in_bias0"])
+        ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+        logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+        ws = torch.empty(ws_floats, device=dev, dtype=torch.float32)
+        N.check(lib.icap_greedy_rnn2_fused_f32(lstm, _ck(t["g_tab0"], "g_tab0"), _ck(g_first, "g_first"), _ck(wd["w_hh"][0], "w_hh0"),
+                                               _ck(t["hh0_bias"], "hh0_bias"), _ck(wd["w_ih"][1], "w_ih1"), _ck(t["ih1_bias"], "ih1_bias"),
+                                               _ck(wd["w_hh"][1], "w_hh1"), _ck(t["hh1_bias"], "hh1_bias"), _ck(wd["fc_w"], "fc_w"),
+                                               _ck(wd["fc_b"], "fc_b"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"), _ck(ws, "ws"),
+                                               NB, H, V, steps, _stream()), "greedy_rnn2_fused")
+        return ids, logits
+    return _graphed_caption(wd, ("rnn2f", NB, steps, bool(want_logits)), (x0,), run)
+
+
+def _rnn_fused_ok(wd: dict, NB: int, I: int) -> bool:
+    H = wd["w_hh"][0].shape[1]
+    return (DECODE_FUSED and NB <= DECODE_FUSED_MAX_NB and len(wd["w_ih"]) == 2 and I == H and H % 4 == 0
+            and wd["w_ih"][1].shape[1] == H)
+
+
 def greedy_rnn(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, ids=None, logits=None, static_ws=False, w16=None):
     """wd: dict with is_lstm, w_ih/w_hh/b_ih/b_hh lists, fc_w, fc_b, in_table.  x0 [NB, I].
     static_ws: the entry point whose workspace lives inside the library (nothing is allocated when `ids` - and `logits`
     if wanted - are passed in); calls that overlap on one GPU share that workspace and must be serialised.
-    w16: stream bf16 copies of the weight matrices (icap_greedy_rnn_w16_f32); None follows decode_weights_bf16()."""
+    w16: stream bf16 copies of the weight matrices (icap_greedy_rnn_w16_f32); None follows decode_weights_bf16().
+    One or two captions of a two-layer decoder with fp32 weights take the two-launches-per-step form (greedy_rnn2_fused)
+    unless the caller passes buffers or set_decode_fused(False)."""
     w16 = decode_weights_bf16() if w16 is None else w16
     if w16 and static_ws:
         raise IcapError("greedy_rnn: the built-in-workspace entry point streams fp32 weights only")
     lib = N.load()
     NB, I = x0.shape
+    if not w16 and not static_ws and ids is None and logits is None and _rnn_fused_ok(wd, NB, I):
+        return greedy_rnn2_fused(wd, x0, steps, want_logits)
     L = len(wd["w_ih"])
     H = wd["w_hh"][0].shape[1]
     V = wd["fc_w"].shape[0]
@@ -1184,13 +1252,43 @@ def greedy_tfm_persist(wd: dict, ca: torch.Tensor, start_ids: torch.Tensor, step
     return ids, logits
 
 
+def greedy_bah_fused(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False):
+    """greedy_bah with one launch per step (icap_greedy_bah_fused_f32): the embedding half of W_ih becomes the table
+    g_tab[v] = W_ih[:, :E] . emb[v] (kept in wd), the context half g_ctx = W_ih[:, E:] . context + b_ih + b_hh is made per
+    call, W_hh . h rides on the vocabulary-projection launch."""
+    lib = N.load()
+    NB, ENC = context.shape
+    V, E = wd["emb"].shape
+    H = wd["w_hh"].shape[1]
+    if "g_tab" not in wd:
+        wd["g_tab"] = linear(wd["emb"], wd["w_ih_e"])
+        wd["b_gates"] = (wd["b_ih"] + wd["b_hh"]).contiguous()
+    dev = context.device
+    ws_floats = lib.icap_greedy_bah_fused_ws_floats(NB, H, V)
+
+    def run(inp):
+        g_ctx = linear(inp[0], wd["w_ih_c"], bias=wd["b_gates"])
+        ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+        logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+        ws = torch.empty(ws_floats, device=dev, dtype=torch.float32)
+        N.check(lib.icap_greedy_bah_fused_f32(_ck(wd["g_tab"], "g_tab"), _ck(g_ctx, "g_ctx"), _ck(wd["w_hh"], "w_hh"), _ck(wd["fc_w"], "fc_w"),
+                                              _ck(wd["fc_scale"], "fc_scale"), _ck(wd["fc_bias"], "fc_bias"),
+                                              _ck(inp[1], "start_ids", torch.int64), _ck(ids, "ids", torch.int64), _ck(logits, "logits"),
+                                              _ck(ws, "ws"), NB, H, V, steps, _stream()), "greedy_bah_fused")
+        return ids, logits
+    return _graphed_caption(wd, ("bahf", NB, ENC, steps, bool(want_logits)), (context, start_ids), run)
+
+
 def greedy_bah(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False, w16=None):
-    """w16: stream bf16 copies of the LSTMCell matrices and fc (icap_greedy_bah_w16_f32); None follows decode_weights_bf16()."""
+    """w16: stream bf16 copies of the LSTMCell matrices and fc (icap_greedy_bah_w16_f32); None follows decode_weights_bf16().
+    One or two captions with fp32 weights take the one-launch-per-step form (greedy_bah_fused) unless set_decode_fused(False)."""
     lib = N.load()
     w16 = decode_weights_bf16() if w16 is None else w16
     NB, ENC = context.shape
     V, E = wd["emb"].shape
     H = wd["w_hh"].shape[1]
+    if not w16 and DECODE_FUSED and NB <= DECODE_FUSED_MAX_NB and H % 4 == 0:
+        return greedy_bah_fused(wd, context, start_ids, steps, want_logits)
     w = N.BahWeights()
     w.E, w.H, w.V = E, H, V
     for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "fc_w", "fc_scale", "fc_bias"):

@@ -440,6 +440,32 @@ int icap_greedy_tfm_w16_f32(const icap_tfm_weights* w, const float* ca, const lo
 int icap_greedy_bah_w16_f32(const icap_bah_weights* w, const float* context, int ENC, const long long* start_ids,
                             long long* ids, float* logits_out, float* ws, int NB, int steps, void* stream);
 
+/* Single-caption latency forms of the recurrent greedy drivers: fewer DEPENDENT launches per step.  The input side of a
+ * cell as a function of the token is one row of a [V][G*H] table made once per weight version (g_tab = W_ih . in(token) +
+ * biases, G = 4 gates for an LSTM, 3 for a GRU); the recurrent side W_hh . h(t) is computed by the launch that projects
+ * h(t) on the vocabulary, as extra row segments, a step ahead of its use; the cell update itself (a gather and a pointwise
+ * step) is redone in the prologue of every workgroup of the next weight-streaming launch.  Results equal the per-cell
+ * drivers' up to the order of the three additions that form a gate pre-activation.  NB <= 8, meant for NB <= 2 (the
+ * prologue is redone by hundreds of workgroups).
+ *
+ * icap_greedy_bah_fused_f32: ONE launch per step for the Bahdanau LSTMCell decoder (icap_greedy_bah_f32: two).
+ *   g_tab [V][4H] = emb . W_ih[:, :E]^T;  g_ctx [NB][4H] = context . W_ih[:, E:]^T + b_ih + b_hh (once per caption);
+ *   w_hh [4H][H]; fc_w [V][H] with fc_scale / fc_bias as in icap_bah_weights.  Same reference lines as icap_greedy_bah_f32
+ *   (TransformerTest_bahdnau.py:166-191 over transformer_word_level_bahdnau.py:127-141).
+ * icap_greedy_rnn2_fused_f32: TWO launches per step for the two-layer LSTM / GRU of DecoderRNN.sample (seq2seqbasic.py:68-91;
+ *   icap_greedy_rnn_f32: three).  g_tab0 [V][G*H] = in_table . W_ih0^T + b_ih0 (LSTM: + b_hh0); g_first [NB][G*H] the same
+ *   for the image feature, step 0's input; hh0_bias / hh1_bias = b_hh of the layer for a GRU (its n gate keeps the two
+ *   halves apart), NULL for an LSTM; ih1_bias = b_ih1 (LSTM: + b_hh1). */
+long long icap_greedy_bah_fused_ws_floats(int NB, int H, int V);
+int icap_greedy_bah_fused_f32(const float* g_tab, const float* g_ctx, const float* w_hh, const float* fc_w,
+                              const float* fc_scale, const float* fc_bias, const long long* start_ids, long long* ids,
+                              float* logits_out, float* ws, int NB, int H, int V, int steps, void* stream);
+long long icap_greedy_rnn2_fused_ws_floats(int NB, int is_lstm, int H, int V);
+int icap_greedy_rnn2_fused_f32(int is_lstm, const float* g_tab0, const float* g_first, const float* w_hh0,
+                               const float* hh0_bias, const float* w_ih1, const float* ih1_bias, const float* w_hh1,
+                               const float* hh1_bias, const float* fc_w, const float* fc_b, long long* ids,
+                               float* logits_out, float* ws, int NB, int H, int V, int steps, void* stream);
+
 /* ------------------------------------------------------------------ training step: losses and optimizer */
 
 /* Masked cross entropy over R rows of V logits.  Row r of the logits lives at

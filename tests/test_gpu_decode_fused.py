@@ -1,0 +1,103 @@
+"""GPU: the latency form of the recurrent greedy drivers (one launch per step for the Bahdanau LSTMCell decoder, two for the
+two-layer LSTM / GRU; icap_greedy_bah_fused_f32 / icap_greedy_rnn2_fused_f32) against the reference's golden captions and
+against the launch-per-cell drivers, at the goldens' small widths and at the widths the reference trains
+(seq2seqbasic.py:194-199, transformer_word_level_bahdnau.py:183-188)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_RTOL = 1e-3       # fp32 sums in another order: relative to the largest logit of the step
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _per_group(run, feats, group):
+    ids, logits = [], []
+    for s in range(0, feats.shape[0], group):
+        i, lg = run(feats[s:s + group].contiguous())
+        ids.append(i)
+        logits.append(lg)
+    return torch.cat(ids, 0), torch.cat(logits, 1)
+
+
+def _close(a, b, what):
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    tol = LOGIT_RTOL * max(1.0, float(np.abs(b).max()))
+    assert np.abs(a - b).max() <= tol, f"{what}: logits differ by {np.abs(a - b).max():.3e} (tolerance {tol:.3e})"
+
+
+def _compare(run, feats, golden, what):
+    """fused (groups of 1 and of 2) against the launch-per-cell driver on the same rows, and against the golden ids."""
+    from image_captioning_amd import ops
+    ops.set_decode_fused(False)
+    try:
+        ids_ref, lg_ref = _per_group(run, feats, 2)
+    finally:
+        ops.set_decode_fused(True)
+    gap = None
+    for group in (1, 2):
+        ids, lg = _per_group(run, feats, group)
+        _close(lg, lg_ref, f"{what} group {group}")
+        # ids may differ from the per-cell driver's only after a step whose top-2 gap is within the logit tolerance
+        top2 = lg_ref.topk(2, dim=-1).values
+        gap = (top2[..., 0] - top2[..., 1]).t().cpu().numpy()                    # [rows, steps]
+        H.assert_ids_match(ids.cpu().numpy(), ids_ref.cpu().numpy(), np.where(gap < 1e-3, 0.0, 1.0), f"{what} group {group} vs per-cell")
+        if golden is not None:
+            H.assert_ids_match(ids.cpu().numpy(), golden["ids_forced"], golden["gaps"], f"{what} group {group} vs golden")
+            _close(lg[:3, 0], torch.from_numpy(golden["logits_img0"]), f"{what} group {group} golden logits")
+    return ids_ref
+
+
+@pytest.mark.parametrize("kind", ["lstm", "gru"])
+def test_rnn2_fused_small(kind):
+    g = H.load(f"seq2seq_{kind}_small")
+    m = H.rnn_decoder(kind, g["dims"]).to(dev())
+    feats = H.features(8, int(g["dims"][0]), 101).to(dev())
+    _compare(lambda f: m.sample_ids(f, 20, want_logits=True), feats, g, f"{kind} fused")
+
+
+def test_bahdanau_fused_small():
+    g = H.load("bahdanau_small")
+    m = H.bah_model(g["dims"]).to(dev())
+    feats = H.features(8, int(g["dims"][1]), 106).to(dev())
+    _compare(lambda f: m.greedy_ids_from_features(f, 20, want_logits=True), feats, g, "bahdanau fused")
+
+
+@pytest.mark.parametrize("kind", ["lstm", "gru"])
+def test_rnn2_fused_reference_widths(kind):
+    """embed 256, hidden 512, two layers, the flickr vocabulary: ragged last vocabulary block (6756 = 422 x 16 + 4)."""
+    m = H.rnn_decoder(kind, (256, 512, 6756, 2)).to(dev())
+    feats = H.features(4, 256, 303).to(dev())
+    ids = _compare(lambda f: m.sample_ids(f, 20, want_logits=True), feats, None, f"{kind} fused 512")
+    assert len(set(ids.flatten().tolist())) > 4
+
+
+def test_bahdanau_fused_reference_widths():
+    m = H.bah_model((512, 512, 512, 256, 6756, 512)).to(dev())
+    feats = H.features(4, 512, 304).to(dev())
+    ids = _compare(lambda f: m.greedy_ids_from_features(f, 10, want_logits=True), feats, None, "bahdanau fused 512")
+    assert len(set(ids.flatten().tolist())) > 2
+
+
+def test_fused_paths_are_taken_and_limits_are_errors():
+    """One and two captions go through the fused entry points (traced), three do not; too many captions is an error."""
+    from image_captioning_amd import ops, _native as N
+    g = H.load("seq2seq_lstm_small")
+    m = H.rnn_decoder("lstm", g["dims"]).to(dev())
+    wd = m._weights()
+    x0 = torch.randn(2, int(g["dims"][1]), device=dev())
+    ops.greedy_rnn(wd, x0, 5)
+    assert "_fused" in wd
+    with pytest.raises(N.IcapError):
+        ops.greedy_rnn2_fused(wd, torch.randn(9, int(g["dims"][1]), device=dev()), 5)
+    m1 = H.rnn_decoder("lstm", (32, 64, 97, 1)).to(dev())
+    wd1 = m1._weights()
+    ops.greedy_rnn(wd1, x0, 5)                       # one layer: the launch-per-cell driver
+    assert "_fused" not in wd1

@@ -281,7 +281,9 @@ class GradientReducer:
     gradient has been accumulated, so the exchange of the late layers' gradients runs while backward is still working
     on the early layers (collectives are launched from autograd's worker thread, in the same order on every rank because
     every rank runs the same graph); ``finish`` launches whatever the hooks did not (buckets holding parameters without
-    a gradient this step) and makes the launch stream wait for all of them.  ``overlap=False`` reduces every bucket in
+    a gradient this step) and makes the launch stream wait for all of them.  ``break_at``: parameter indices at which a
+    bucket must start whatever its size (the staged-graph trainer puts one where the CNN's parameters end, so that no bucket
+    straddles the two backward graphs).  ``overlap=False`` reduces every bucket in
     ``finish``, after backward, from the thread that called ``step``.  ``overlap=None`` (the default) picks by backend:
     True for gloo, whose hook path is exercised by the two-rank tests, and False for RCCL ("nccl") unless the
     environment sets ICAP_DP_OVERLAP=1 - the hook path HAS NOT YET RUN OVER RCCL on real multi-GPU hardware (collectives
@@ -298,7 +300,7 @@ class GradientReducer:
     CPU tensors (the gloo unit tests) go to gloo directly.
     """
 
-    def __init__(self, flat, group=None, bucket_mb: float = 16.0, overlap=None):
+    def __init__(self, flat, group=None, bucket_mb: float = 16.0, overlap=None, break_at=()):
         import os
         import torch.distributed as dist
         self.dist = dist
@@ -317,7 +319,7 @@ class GradientReducer:
         for i in reversed(range(len(optimizer.params))):
             cur_lo = optimizer.offsets[i]
             idxs.append(i)
-            if hi - cur_lo >= per or i == 0:
+            if hi - cur_lo >= per or i == 0 or i in break_at:       # break_at: parameter indices a bucket must start at
                 b = len(self.buckets)
                 self.buckets.append((cur_lo, hi))
                 for j in idxs:
@@ -375,8 +377,45 @@ class GradientReducer:
         else:
             self.handles.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def launch_buckets(self, buckets):
+        """Start the exchange of these buckets now, from the calling thread (the staged-graph step calls this between two
+        graph replays with the buckets the first graph has completed).  With the host-staged stand-in the host all-reduce
+        of what has been launched so far can be run right away by ``reduce_staged``; RCCL needs nothing more."""
+        for b in buckets:
+            if not self.launched[b]:
+                self._launch(b)
+
+    def reduce_staged(self):
+        """Host-staged backend only: reduce the buckets whose device-to-host copies have been launched so far and start
+        their copies back, all beside whatever the launch stream is running; ``finish`` orders the launch stream after
+        them.  (The caller has queued later work on the launch stream already, so the host blocks here on the COPIES'
+        event, not on that work.)"""
+        if not self.host_staged or not self.staged:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.comm_stream)
+        ev.synchronize()
+        with torch.cuda.stream(self.comm_stream):
+            for b in self.staged:                                # same order on every rank
+                self.dist.all_reduce(self.host[b], op=self.dist.ReduceOp.SUM, group=self.group)
+                lo, hi = self.buckets[b]
+                self.opt.flat_g[lo:hi].copy_(self.host[b], non_blocking=True)
+        self.staged = []
+        self.early_reduced = True
+
+    def buckets_within(self, param_indices):
+        """Buckets all of whose parameters are in ``param_indices`` (indices into the optimizer's parameter list), in
+        launch order (the order backward fills them)."""
+        inside = set(param_indices)
+        whole = [True] * len(self.buckets)
+        for j, b in self.bucket_of.items():
+            if j not in inside:
+                whole[b] = False
+        return [b for b in range(len(self.buckets)) if whole[b]]
+
     def prepare(self):
         """Call before backward of every step."""
+        self.early_reduced = False
         self.pending = [0] * len(self.buckets)
         self.fired = [False] * len(self.fired)
         self.launched = [False] * len(self.buckets)
@@ -402,6 +441,8 @@ class GradientReducer:
                 lo, hi = self.buckets[b]
                 self.opt.flat_g[lo:hi].copy_(self.host[b], non_blocking=True)
             self.staged = []
+            if getattr(self, "early_reduced", False):            # copies back started by reduce_staged run on the side stream
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.handles = []
 
 
@@ -428,12 +469,25 @@ class Trainer:
         self.dtype = dtype                   # "bf16": bf16 products in forward and input gradients, fp32 master weights
                                              # / accumulation / weight gradients / optimizer (ops.train_step)
         self.opt = AdamW(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        if self.graph and overlap:
-            raise ValueError("Trainer(graph=True): the gradient exchange runs between the two recorded graphs; overlap=True is not supported")
-        if overlap is None and self.graph:   # hooks do not run in a replay; otherwise the reducer picks by backend
+        # graph=True: hooks do not run in a replay, so the reducer's hook path stays off; "overlap" then means the STAGED
+        # step - the backward recorded as two graphs split where the gradient reaches the CNN's output, the finished buckets'
+        # exchange launched between the two replays (see _graph_step).  Default on; overlap=False keeps the exchange after
+        # the whole backward.
+        self._want_staged = self.graph and overlap is not False
+        if self.graph:
             overlap = False
-        self.reducer = GradientReducer(self.opt, group=group, bucket_mb=bucket_mb, overlap=overlap) if dist.is_available() and dist.is_initialized() else None
+        break_at = ()
+        if self._want_staged and hasattr(model, "cnn_model"):
+            cnn = {id(p) for p in model.cnn_model.parameters()}
+            idx = [i for i, p in enumerate(self.opt.params) if id(p) not in cnn]
+            break_at = (idx[0],) if idx and idx[0] > 0 else ()
+        self.reducer = GradientReducer(self.opt, group=group, bucket_mb=bucket_mb, overlap=overlap, break_at=break_at) if dist.is_available() and dist.is_initialized() else None
         self.loss_kind = loss
+        self.staged = (self._want_staged and self.reducer is not None and self.reducer.world > 1
+                       and hasattr(model, "cnn_model") and hasattr(model, "forward_features")
+                       and any(p.requires_grad for p in model.cnn_model.parameters()))
+        self._graph_cnn, self._early_buckets = None, []
+        self.timeline = None                 # a list: the staged step appends its events to it (tools/train_rehearse.py)
 
     def _forward_backward(self, images, captions, padding_idx, exchange=True):
         exchange = exchange and self.reducer is not None
@@ -443,14 +497,16 @@ class Trainer:
             self.reducer.prepare()
         with ops.train_step(self.dtype):      # per-step weight copies live until backward is done
             predictions = self.model(images, captions)
-            if self.loss_kind == "compute_loss":
-                loss = compute_loss(predictions[:, :-1], captions[:, 1:], padding_idx)
-            else:
-                loss = CrossEntropyLoss(ignore_index=padding_idx)(predictions.reshape(-1, predictions.size(-1)), captions.reshape(-1))
+            loss = self._loss_of(predictions, captions, padding_idx)
             loss.backward()
         if exchange:
             self.reducer.finish()
         return loss.detach()
+
+    def _loss_of(self, predictions, captions, padding_idx):
+        if self.loss_kind == "compute_loss":
+            return compute_loss(predictions[:, :-1], captions[:, 1:], padding_idx)
+        return CrossEntropyLoss(ignore_index=padding_idx)(predictions.reshape(-1, predictions.size(-1)), captions.reshape(-1))
 
     def step(self, images, captions, padding_idx):
         if self.graph:
@@ -464,8 +520,11 @@ class Trainer:
     # the third call records zero_grad + forward + loss + backward + AdamW into a graph on static input buffers; from
     # then on a step is two copies into those buffers and one graph launch.  What changes from step to step lives in
     # device memory and is advanced inside the graph: the dropout generator's offset base and AdamW's step count.
-    # Under data parallelism the step is two graphs - everything up to the gradients, and the optimizer - with the
-    # gradient exchange launched between them in the ordinary way, so no collective is ever recorded.
+    # Under data parallelism no collective is ever recorded: the step is THREE graphs - forward + backward down to the CNN's
+    # output | the CNN's backward | the optimizer - and the exchange is launched between the replays in the ordinary way:
+    # the buckets the first graph completes (decoder, encoder block: three quarters of the gradient bytes of the Bahdanau
+    # captioner) travel while the second graph runs, the rest after it.  overlap=False, or a model without a trainable
+    # `cnn_model` / `forward_features`, keeps two graphs with the whole exchange between them.
     def _graph_step(self, images, captions, padding_idx):
         if self._graph is None:
             if self._eager_steps < 2:
@@ -482,6 +541,23 @@ class Trainer:
         self._graph.replay()
         if self._graph_opt is not None:
             self.reducer.prepare()
+            if self._graph_cnn is not None:
+                # staged: the decoder / encoder-block buckets are complete - their exchange runs under the CNN's backward
+                tl = self.timeline
+                if tl is not None:
+                    e_first = torch.cuda.Event(enable_timing=True)
+                    e_first.record()
+                self.reducer.launch_buckets(self._early_buckets)
+                if tl is not None:
+                    e_sent = torch.cuda.Event(enable_timing=True)
+                    e_sent.record(self.reducer.comm_stream if self.reducer.comm_stream is not None else torch.cuda.current_stream())
+                self._graph_cnn.replay()
+                if tl is not None:
+                    e_cnn = torch.cuda.Event(enable_timing=True)
+                    e_cnn.record()
+                self.reducer.reduce_staged()
+                if tl is not None:       # (events, was the CNN's backward still running when the early buckets' host reduction returned)
+                    tl.append((e_first, e_sent, e_cnn, not e_cnn.query()))
             self.reducer.finish()
             self._graph_opt.replay()
         DropoutState.offset += self._draws_per_step
@@ -508,11 +584,31 @@ class Trainer:
             self._draws_per_step = DropoutState.offset - o0
             self._offset_base.add_(self._draws_per_step)
 
+        graph_cnn = torch.cuda.CUDAGraph() if self.staged else None
         try:
-            with torch.cuda.graph(graph):
-                self._loss = self._forward_backward(self._images, self._caps, padding_idx, exchange=False)
-                if graph_opt is None:
-                    record_optimizer()
+            if graph_cnn is None:
+                with torch.cuda.graph(graph):
+                    self._loss = self._forward_backward(self._images, self._caps, padding_idx, exchange=False)
+                    if graph_opt is None:
+                        record_optimizer()
+            else:
+                # Three graphs.  1: zero_grad, forward, loss, backward down to the CNN's output (the gradient stops at a
+                # detached leaf standing for that output); 2: the CNN's backward from the leaf's gradient, recorded into the
+                # first graph's memory pool - it reads the activations the first graph saved; 3: the optimizer.  The
+                # per-step weight copies (ops.train_step) stay alive across both backward recordings.
+                self.model.train()
+                with ops.train_step(self.dtype):
+                    with torch.cuda.graph(graph):
+                        self.opt.zero_grad()
+                        feats = self.model.cnn_model(self._images)
+                        leaf = feats.detach().requires_grad_()
+                        predictions = self.model.forward_features(leaf, self._caps)
+                        loss = self._loss_of(predictions, self._caps, padding_idx)
+                        loss.backward()
+                        self._loss = loss.detach()
+                    with torch.cuda.graph(graph_cnn, pool=graph.pool()):
+                        feats.backward(leaf.grad)
+                    del feats, leaf, predictions, loss
             if graph_opt is not None:
                 with torch.cuda.graph(graph_opt):
                     record_optimizer()
@@ -521,4 +617,7 @@ class Trainer:
             ops.AUTOTUNE = tune
         DropoutState.offset = o0                          # recording ran nothing: the first replay makes these draws
         self._touched = list(self.opt.flat.touched)
-        self._graph, self._graph_opt = graph, graph_opt
+        self._graph, self._graph_opt, self._graph_cnn = graph, graph_opt, graph_cnn
+        if graph_cnn is not None:
+            cnn = {id(p) for p in self.model.cnn_model.parameters()}
+            self._early_buckets = self.reducer.buckets_within([i for i, p in enumerate(self.opt.params) if id(p) not in cnn])

@@ -34,4 +34,13 @@ def test_two_ranks_on_different_batches_stay_in_step():
 
 def test_exchange_after_backward_and_graph_replayed_step():
     _rehearse(29563, REH_SAME=1, REH_OVERLAP=0)
-    _rehearse(29564, REH_SAME=1, REH_GRAPH=1, REH_STEPS=5)
+    _rehearse(29564, REH_SAME=1, REH_GRAPH=1, REH_OVERLAP=0, REH_STEPS=5)         # two graphs, the whole exchange between them
+
+
+def test_staged_graph_step_exchanges_the_decoder_buckets_under_the_cnn_backward():
+    """graph=True under data parallelism: three graphs (forward + backward to the CNN's output | CNN backward | optimizer);
+    the buckets the first completes are launched between the two backward replays.  Parameters after 5 steps (2 eager, the
+    recording, 2 replays) equal the single-process one-graph trainer's bit for bit; different batches stay in step."""
+    out = _rehearse(29565, REH_SAME=1, REH_GRAPH=1, REH_STEPS=5)
+    assert "graph step staged: True" in out and "max diff 0.000e+00" in out
+    _rehearse(29566, REH_SAME=0, REH_GRAPH=1, REH_STEPS=6)

@@ -11,7 +11,7 @@ Checks, per rank:
   REH_SAME=0: ranks train on different batches; the parameters must be identical across ranks afterwards.
 
 usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/train_rehearse.py
-env: REH_OVERLAP=1|0, REH_GRAPH=0|1, REH_STEPS, REH_BATCH, REH_VOCAB, REH_BUCKET_MB"""
+env: REH_OVERLAP=1|0 (with REH_GRAPH=1: staged three-graph step | exchange after the whole backward), REH_GRAPH=0|1, REH_STEPS, REH_BATCH, REH_VOCAB, REH_BUCKET_MB"""
 import faulthandler
 import os
 import sys
@@ -37,6 +37,8 @@ def run(rank, same, steps, B, V, graph, overlap, bucket_mb):
     batches = [(synthetic_images(B, seed=5 + off + 10 * i).cuda(), synthetic_captions(B, 8, V, 2, 3, 0, seed=7 + off + 10 * i).cuda()) for i in range(2)]
     orders = []
     for i in range(steps):
+        if os.environ.get("REH_TIMELINE") == "1" and i == steps - 1:
+            tr.timeline = []
         loss = tr.step(*batches[i % 2], 0)
         if tr.reducer is not None:
             orders.append((list(tr.reducer.launch_order), tr.reducer.hooked))
@@ -51,7 +53,8 @@ def main():
     same = os.environ.get("REH_SAME", "1") == "1"
     steps, B, V = int(os.environ.get("REH_STEPS", "4")), int(os.environ.get("REH_BATCH", "4")), int(os.environ.get("REH_VOCAB", "300"))
     graph = os.environ.get("REH_GRAPH", "0") == "1"
-    overlap = None if graph else os.environ.get("REH_OVERLAP", "1") == "1"
+    want = os.environ.get("REH_OVERLAP", "1") == "1"
+    overlap = (None if want else False) if graph else want        # graph mode: None = the staged three-graph step
     bucket_mb = float(os.environ.get("REH_BUCKET_MB", "1.0"))
     t0 = time.perf_counter()
     ref = run(rank, same, steps, B, V, graph, overlap, bucket_mb)[0] if same else None      # no process group yet: single process
@@ -68,6 +71,17 @@ def main():
         ok = ok and hooked
         print(f"[r{rank}] launch order (first 8): {orders[0][0][:8]}, launched by hooks during backward: {orders[0][1]} of {len(red.buckets)}, "
               f"every bucket once and same order each step: {hooked}", file=sys.stderr, flush=True)
+    if graph:
+        staged = tr._graph_cnn is not None
+        ok = ok and staged == want and (not staged or (len(tr._early_buckets) >= 1 and orders[-1][0][:len(tr._early_buckets)] == tr._early_buckets))
+        print(f"[r{rank}] graph step staged: {staged} (wanted {want}); buckets launched between the backward graphs: "
+              f"{len(tr._early_buckets)} of {len(red.buckets)}", file=sys.stderr, flush=True)
+    if graph and tr.timeline:
+        torch.cuda.synchronize()
+        e_first, e_sent, e_cnn, running = tr.timeline[-1]
+        print(f"[r{rank}] staged step timeline (ms after the first backward graph): early buckets' device-to-host copies done at "
+              f"{e_first.elapsed_time(e_sent):.3f}, CNN backward graph done at {e_first.elapsed_time(e_cnn):.3f}; CNN backward still running when the "
+              f"early buckets' all-reduce returned on the host: {running}", file=sys.stderr, flush=True)
     if same:
         err = float((flat - ref).abs().max())
         scale = float(ref.abs().max())

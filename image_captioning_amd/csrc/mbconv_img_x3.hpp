@@ -587,7 +587,6 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
             }
         }
     };
-    auto item_steps = [](int item) { return item < KS ? ROW_STEPS : EPI_STEPS; };
 
     auto pooled_reduce = [&](int chunk) {
         if (!pooled || tid >= XCH) return;

@@ -101,3 +101,39 @@ def test_fused_paths_are_taken_and_limits_are_errors():
     wd1 = m1._weights()
     ops.greedy_rnn(wd1, x0, 5)                       # one layer: the launch-per-cell driver
     assert "_fused" not in wd1
+
+
+@pytest.mark.parametrize("nb", [3, 5, 8])
+def test_fused_entry_points_with_wider_groups(nb):
+    """The C entry points take up to 8 captions (the Python drivers route at most 2 to them): groups of 3 / 5 / 8 exercise the
+    LDS-staged arg-max partials and the cell loop over more elements than threads, against the launch-per-cell drivers."""
+    from image_captioning_amd import ops
+    d = dev()
+    for kind in ("lstm", "gru"):
+        m = H.rnn_decoder(kind, (256, 512, 6756, 2)).to(d)
+        wd = m._weights()
+        x0 = ops.linear(H.features(nb, 256, 41 + nb).to(d), wd["ff_w"], bias=wd["ff_b"])
+        ids, lg = ops.greedy_rnn2_fused(wd, x0, 12, want_logits=True)
+        ops.set_decode_fused(False)
+        try:
+            ids_ref, lg_ref = ops.greedy_rnn(wd, x0, 12, want_logits=True)
+        finally:
+            ops.set_decode_fused(True)
+        _close(lg, lg_ref, f"{kind} fused nb={nb}")
+        top2 = lg_ref.topk(2, dim=-1).values
+        gap = (top2[..., 0] - top2[..., 1]).t().cpu().numpy()
+        H.assert_ids_match(ids.cpu().numpy(), ids_ref.cpu().numpy(), np.where(gap < 1e-3, 0.0, 1.0), f"{kind} fused nb={nb}")
+    mb = H.bah_model((512, 512, 512, 256, 6756, 512)).to(d)
+    p = mb.decoder._weights()
+    ctx = mb.encoder.rows_forward(H.features(nb, 512, 51 + nb).to(d))
+    start = torch.full((nb,), 2, device=d, dtype=torch.int64)
+    ids, lg = ops.greedy_bah_fused(p, ctx, start, 10, want_logits=True)
+    ops.set_decode_fused(False)
+    try:
+        ids_ref, lg_ref = ops.greedy_bah(p, ctx, start, 10, want_logits=True)
+    finally:
+        ops.set_decode_fused(True)
+    _close(lg, lg_ref, f"bahdanau fused nb={nb}")
+    top2 = lg_ref.topk(2, dim=-1).values
+    gap = (top2[..., 0] - top2[..., 1]).t().cpu().numpy()
+    H.assert_ids_match(ids.cpu().numpy(), ids_ref.cpu().numpy(), np.where(gap < 1e-3, 0.0, 1.0), f"bahdanau fused nb={nb}")

@@ -427,6 +427,46 @@ def decode_b1(torch, dev):
         gbs = DECODE_PARAMS["char_transformer"] * 4 / us / 1e3
         out["char_transformer"][label] = {"us_per_step": us, "bytes_per_step": DECODE_PARAMS["char_transformer"] * 4, "achieved_gbs": gbs,
                                          "hbm_frac": gbs / HBM_PEAK_GBS}
+    # the decoder calls alone, without the per-image work in front of them (encoder block over the image's row, cross-attention /
+    # feature projection: ~10 launches per caption that the model-level figures above include)
+    st1 = torch.full((1,), 2, device=dev, dtype=torch.int64)
+    for kind in ("lstm", "gru"):
+        m = [j for j in jobs if j[0] == kind][0][1].__defaults__[0]
+        wd_r = m._weights()
+        x0 = _ops.linear(f256, wd_r["ff_w"], bias=wd_r["ff_b"])
+        out[kind]["decoder_call_only_us_per_step"] = timeit(lambda: _ops.greedy_rnn(wd_r, x0, CAPTION_LEN)) * 1e3 / CAPTION_LEN
+    wd_t = wm._greedy_weights()
+    ca1 = wm.decoder.cross_attention_single(wm.encoder.forward_independent(f512))
+    out["word_transformer"]["decoder_call_only_us_per_step"] = timeit(lambda: _ops.greedy_tfm(wd_t, ca1, st1, CAPTION_LEN)) * 1e3 / CAPTION_LEN
+    try:
+        ok_ids = bool(torch.equal(_ops.greedy_tfm_persist(wd_t, ca1, st1, CAPTION_LEN)[0], _ops.greedy_tfm(wd_t, ca1, st1, CAPTION_LEN)[0]))
+        out["word_transformer"]["persistent"] = {
+            "decoder_call_only_us_per_step": timeit(lambda: _ops.greedy_tfm_persist(wd_t, ca1, st1, CAPTION_LEN, check=False)) * 1e3 / CAPTION_LEN,
+            "ids_equal_default_path": ok_ids}
+    except Exception as e:      # noqa: BLE001
+        out["word_transformer"]["persistent"] = {"error": f"{type(e).__name__}: {e}"}
+    # the LSTMCell decoder's caption as one persistent launch (weights LDS-resident, one exchange between workgroups per step)
+    try:
+        same = bool(torch.equal(bm.greedy_ids_from_features(f512, CAPTION_LEN, mode="persistent"), bm.greedy_ids_from_features(f512, CAPTION_LEN)))
+        ms = timeit(lambda: bm.greedy_ids_from_features(f512, CAPTION_LEN, mode="persistent", check=False))
+        us = ms * 1e3 / CAPTION_LEN
+        # the decoder call alone (encoder-block rows of the image computed beforehand): at 133 us of GPU time per caption the
+        # model-level call above is bound by the host's ~10 launches in front of the decoder, not by the decoder
+        pw = bm.decoder._weights()
+        ctx1 = bm.encoder.rows_forward(f512)
+        st1 = torch.full((1,), bm.start_token, device=dev, dtype=torch.int64)
+        us_dec = timeit(lambda: _ops.greedy_bah_persist(pw, ctx1, st1, CAPTION_LEN, check=False)) * 1e3 / CAPTION_LEN
+        us_dec_fused = timeit(lambda: _ops.greedy_bah(pw, ctx1, st1, CAPTION_LEN)) * 1e3 / CAPTION_LEN
+        gbs = DECODE_PARAMS["bahdanau"] * 4 / us / 1e3
+        out["bahdanau"]["persistent"] = {"us_per_step": us, "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                                         "decoder_call_only": {"us_per_step": us_dec, "hbm_frac": DECODE_PARAMS["bahdanau"] * 4 / us_dec / 1e3 / HBM_PEAK_GBS,
+                                                               "default_path_us_per_step": us_dec_fused},
+                                         "ids_equal_default_path": same,
+                                         "note": "one launch per caption incl. its set-up (18 MB of weights into LDS, exchange buffers cleared); timed "
+                                                 "without the read-back of the ids that detects a launch which could not run (checked once before); "
+                                                 "opt-in (mode=\"persistent\"): needs the device to itself"}
+    except Exception as e:      # noqa: BLE001 - a secondary figure must not take the line down
+        out["bahdanau"]["persistent"] = {"error": f"{type(e).__name__}: {e}"}
     out["note"] = ("one caption in flight, fp32 weights, whole caption enqueued without host round trips; bytes = parameters touched per step x 4; "
                    "the char model's default (table) path is reported as captions/s and us per step-equivalent (caption time / 58): its weights are read once per caption; its bandwidth figures are those of the step-by-step forms (steps: one launch chain per step; persistent: one launch per caption)")
     return out

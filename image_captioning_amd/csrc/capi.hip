@@ -35,6 +35,10 @@ int greedy_rnn2_fused_f32(int, const float*, const float*, const float*, const f
 int greedy_tfm_persist_max_nb(int, int, int);
 long long greedy_tfm_persist_ws_bytes(int, int, int, int);
 int greedy_tfm_persist_f32(const icap_tfm_weights*, const float*, const long long*, long long*, float*, void*, int, int, hipStream_t);
+int greedy_bah_persist_max_nb(int, int);
+long long greedy_bah_persist_ws_bytes(int, int, int);
+int greedy_bah_persist_f32(const float*, const float*, const float*, const float*, const float*, const float*, const long long*, long long*,
+                           float*, void*, int, int, int, int, hipStream_t);
 int conv_igemm_use_tuned(int);
 int conv_igemm_cfg_f32(const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int,
                        int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -614,6 +618,14 @@ int icap_table_walk(const long long* next, const long long* start, long long* id
     return table_walk(next, start, ids, logits_tab, ldl, logits_out, V, B, steps, (hipStream_t)stream);
 }
 
+int icap_greedy_bah_persist_max_nb(int H, int V) { return greedy_bah_persist_max_nb(H, V); }
+long long icap_greedy_bah_persist_ws_bytes(int NB, int H, int V) { return greedy_bah_persist_ws_bytes(NB, H, V); }
+int icap_greedy_bah_persist_f32(const float* g_tab, const float* g_ctx, const float* w_hh, const float* fc_w, const float* fc_scale,
+                                const float* fc_bias, const long long* start_ids, long long* ids, float* logits_out, void* ws,
+                                int NB, int H, int V, int steps, void* stream) {
+    return greedy_bah_persist_f32(g_tab, g_ctx, w_hh, fc_w, fc_scale, fc_bias, start_ids, ids, logits_out, ws, NB, H, V, steps,
+                                  (hipStream_t)stream);
+}
 int icap_greedy_tfm_persist_max_nb(int E, int FF, int V) { return greedy_tfm_persist_max_nb(E, FF, V); }
 long long icap_greedy_tfm_persist_ws_bytes(int NB, int E, int FF, int V) { return greedy_tfm_persist_ws_bytes(NB, E, FF, V); }
 int icap_greedy_tfm_persist_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,

@@ -140,10 +140,32 @@ __global__ __launch_bounds__(PT) void tfm_persist_kernel(const PersistArgs a) {
             }
         }
         // ---- phase 2: gather h, y rows = fc2 h + b2 + x
-        for (int i = tid; i < NBT * FF; i += PT) {
-            unsigned long long w;
-            if (!consume(a.hbuf + i, tag1, 0, w)) { s_fail = 1; break; }
-            h[i] = __uint_as_float((unsigned)w);
+        // four words per thread are requested before any is looked at (one round trip, not four); a word that has not
+        // landed yet is asked for again
+        for (int i0 = tid; i0 < NBT * FF; i0 += 4 * PT) {
+            unsigned long long w[4];
+            unsigned spins = 0;
+            bool all;
+            do {
+                all = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = min(i0 + k * PT, NBT * FF - 1);
+                    w[k] = __hip_atomic_load(a.hbuf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) all = all && (unsigned)(w[k] >> 32) == tag1;
+                if (!all) {
+                    if (++spins > P_SPIN_LIMIT) { s_fail = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            } while (!all);
+            if (!all) break;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * PT;
+                if (i < NBT * FF) h[i] = __uint_as_float((unsigned)w[k]);
+            }
         }
         __syncthreads();
         if (s_fail) { ok = false; break; }

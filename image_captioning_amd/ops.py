@@ -1279,6 +1279,38 @@ def greedy_bah_fused(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, s
     return _graphed_caption(wd, ("bahf", NB, ENC, steps, bool(want_logits)), (context, start_ids), run)
 
 
+def greedy_bah_persist_max_nb(H: int, V: int) -> int:
+    """Captions per call of the persistent whole-caption LSTMCell decoder for this shape; 0 = not supported."""
+    return N.load().icap_greedy_bah_persist_max_nb(H, V)
+
+
+def greedy_bah_persist(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False, check=True):
+    """greedy_bah_fused as ONE persistent launch with the vocabulary projection and W_hh resident in LDS
+    (icap_greedy_bah_persist_f32).  The kernel needs all its workgroups resident at once (a plain launch on an otherwise idle
+    device); a launch that could not make progress gives up after a bounded spin and leaves -1 in every id.  check=True (the
+    default) reads the ids back - one host synchronisation - and raises IcapError for such a launch."""
+    lib = N.load()
+    NB, ENC = context.shape
+    V, E = wd["emb"].shape
+    H = wd["w_hh"].shape[1]
+    if "g_tab" not in wd:
+        wd["g_tab"] = linear(wd["emb"], wd["w_ih_e"])
+        wd["b_gates"] = (wd["b_ih"] + wd["b_hh"]).contiguous()
+    dev = context.device
+    g_ctx = linear(context, wd["w_ih_c"], bias=wd["b_gates"])
+    ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
+    logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
+    ws = torch.empty((lib.icap_greedy_bah_persist_ws_bytes(NB, H, V) + 7) // 8, device=dev, dtype=torch.int64)
+    N.check(lib.icap_greedy_bah_persist_f32(_ck(wd["g_tab"], "g_tab"), _ck(g_ctx, "g_ctx"), _ck(wd["w_hh"], "w_hh"), _ck(wd["fc_w"], "fc_w"),
+                                            _ck(wd["fc_scale"], "fc_scale"), _ck(wd["fc_bias"], "fc_bias"),
+                                            _ck(start_ids, "start_ids", torch.int64), _ck(ids, "ids", torch.int64), _ck(logits, "logits"),
+                                            ws.data_ptr(), NB, H, V, steps, _stream()), "greedy_bah_persist")
+    if check and bool((ids < 0).any().item()):
+        raise IcapError("greedy_bah_persist: the persistent launch could not make progress (its workgroups were not all resident); "
+                        "use greedy_bah")
+    return ids, logits
+
+
 def greedy_bah(wd: dict, context: torch.Tensor, start_ids: torch.Tensor, steps: int, want_logits=False, w16=None):
     """w16: stream bf16 copies of the LSTMCell matrices and fc (icap_greedy_bah_w16_f32); None follows decode_weights_bf16().
     One or two captions with fp32 weights take the one-launch-per-step form (greedy_bah_fused) unless set_decode_fused(False)."""

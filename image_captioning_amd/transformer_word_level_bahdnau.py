@@ -180,15 +180,30 @@ class ImageCaptioningModel(nn.Module):
         encoder_out = self.encoder(img_features.unsqueeze(1))
         return self.decoder(captions, encoder_out)
 
-    def greedy_ids_from_features(self, img_features, max_len, want_logits=False, lockstep=None):
+    def greedy_ids_from_features(self, img_features, max_len, want_logits=False, lockstep=None, mode=None, check=True):
         """Greedy decoding of every image as its own batch of one (generate_caption of
         TransformerTest_bahdnau.py:153-191 with argmax): the attention weight over a single image is 1, the
-        context is that image's encoder row, and re-running the growing prefix equals carrying (h, c)."""
+        context is that image's encoder row, and re-running the growing prefix equals carrying (h, c).
+        mode="persistent": whole captions as single launches with LDS-resident weights (ops.greedy_bah_persist; opt-in: it needs
+        the device to itself and - unless check=False - reads the ids back to detect a launch that could not run, which shows as ids of -1)."""
         require_eval(self, "ImageCaptioningModel")
         p = self.decoder._weights()
         ctx = self.encoder.rows_forward(img_features)                                        # [B, E]
         B = ctx.shape[0]
         start = torch.full((B,), self.start_token, device=ctx.device, dtype=torch.int64)
+        if mode == "persistent":
+            nb = ops.greedy_bah_persist_max_nb(self.decoder.decoder_dim, p["fc_w"].shape[0])
+            if nb == 0:
+                raise ops.IcapError("persistent decoder: shape not supported")
+            ids, logits = [], []
+            for s in range(0, B, nb):
+                i, lg = ops.greedy_bah_persist(p, ctx[s:s + nb].contiguous(), start[s:s + nb].contiguous(), max_len, want_logits, check=check)
+                ids.append(i)
+                logits.append(lg)
+            ids = torch.cat(ids, 0)
+            return (ids, torch.cat(logits, 1)) if want_logits else ids
+        if mode not in (None, "steps"):
+            raise ValueError(f"unknown mode {mode!r}")
         lock = MAX_LOCKSTEP if lockstep is None else lockstep
         if B <= lock:
             ids, logits = [], []

@@ -409,6 +409,21 @@ long long icap_greedy_tfm_persist_ws_bytes(int NB, int E, int FF, int V);
 int icap_greedy_tfm_persist_f32(const icap_tfm_weights* w, const float* ca, const long long* start_ids, long long* ids,
                                 float* logits_out, void* ws, int NB, int steps, void* stream);
 
+/* The Bahdanau LSTMCell decoder's greedy caption (icap_greedy_bah_fused_f32's step: table row for the token-fed input side,
+ * W_hh . h computed a step ahead) as ONE persistent launch: the vocabulary projection and W_hh stay in the LDS of one
+ * workgroup per CU for all `steps`, and a step is a single exchange of {value, tag} words between the workgroups (partial
+ * arg-max words polled, the 4H recurrent values read once and verified by tag; double-buffered by step parity).  Operands as
+ * icap_greedy_bah_fused_f32 (g_tab [V][4H], g_ctx [NB][4H], w_hh [4H][H], fc_w [V][H], optional fc_scale / fc_bias).
+ * icap_greedy_bah_persist_max_nb: captions per call (at most 2; 0 = the shape does not fit the chip's LDS);
+ * ws: icap_greedy_bah_persist_ws_bytes bytes, 8-byte aligned, cleared by the call.  The grid must be co-resident (a plain
+ * launch on an otherwise idle device); if a workgroup cannot make progress a bounded spin ends the launch and every id is -1.
+ * Replaces the generate_caption loop of TransformerTest_bahdnau.py:153-191 (argmax form) for one image. */
+int icap_greedy_bah_persist_max_nb(int H, int V);
+long long icap_greedy_bah_persist_ws_bytes(int NB, int H, int V);
+int icap_greedy_bah_persist_f32(const float* g_tab, const float* g_ctx, const float* w_hh, const float* fc_w, const float* fc_scale,
+                                const float* fc_bias, const long long* start_ids, long long* ids, float* logits_out, void* ws,
+                                int NB, int H, int V, int steps, void* stream);
+
 typedef struct {
     int E, H, V;                             /* embed dim, decoder dim, vocab */
     const float* emb;                        /* [V][E] */

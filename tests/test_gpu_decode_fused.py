@@ -137,3 +137,33 @@ def test_fused_entry_points_with_wider_groups(nb):
     top2 = lg_ref.topk(2, dim=-1).values
     gap = (top2[..., 0] - top2[..., 1]).t().cpu().numpy()
     H.assert_ids_match(ids.cpu().numpy(), ids_ref.cpu().numpy(), np.where(gap < 1e-3, 0.0, 1.0), f"bahdanau fused nb={nb}")
+
+
+def test_bahdanau_persistent_caption():
+    """The whole caption as one persistent launch (icap_greedy_bah_persist_f32): golden ids at the small widths, and at the
+    reference's widths ids / logits against the launch-per-cell driver, one and two captions per launch, twice in a row (the
+    exchange buffers are cleared per call)."""
+    from image_captioning_amd import ops
+    g = H.load("bahdanau_small")
+    m = H.bah_model(g["dims"]).to(dev())
+    feats = H.features(8, int(g["dims"][1]), 106).to(dev())
+    ids, lg = m.greedy_ids_from_features(feats, 20, want_logits=True, mode="persistent")
+    H.assert_ids_match(ids.cpu().numpy(), g["ids_forced"], g["gaps"], "bahdanau persistent vs golden")
+    _close(lg[:3, 0], torch.from_numpy(g["logits_img0"]), "bahdanau persistent golden logits")
+    mb = H.bah_model((512, 512, 512, 256, 6756, 512)).to(dev())
+    feats = H.features(5, 512, 304).to(dev())
+    ops.set_decode_fused(False)
+    try:
+        ids_ref, lg_ref = mb.greedy_ids_from_features(feats, 12, want_logits=True)
+    finally:
+        ops.set_decode_fused(True)
+    top2 = lg_ref.topk(2, dim=-1).values
+    gap = (top2[..., 0] - top2[..., 1]).t().cpu().numpy()
+    for rep in range(2):
+        ids, lg = mb.greedy_ids_from_features(feats, 12, want_logits=True, mode="persistent")
+        _close(lg, lg_ref, f"bahdanau persistent 512 (call {rep})")
+        H.assert_ids_match(ids.cpu().numpy(), ids_ref.cpu().numpy(), np.where(gap < 1e-3, 0.0, 1.0), f"bahdanau persistent 512 (call {rep})")
+    p = mb.decoder._weights()
+    assert ops.greedy_bah_persist_max_nb(512, 6756) == 2
+    with pytest.raises(ops.IcapError):
+        ops.greedy_bah_persist(p, torch.zeros(3, 512, device=dev()), torch.full((3,), 2, device=dev(), dtype=torch.int64), 4)

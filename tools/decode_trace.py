@@ -28,6 +28,11 @@ if which == "bahdanau":
     bm = seeded(bah.ImageCaptioningModel(Pass(), bah.TransformerEncoderBlock(512, 512, 8, dropout=0.5),
                                          bah.BahdanauDecoder(512, 512, 512, 256, bench.VOCAB, dropout=0.5)), 31)
     fn = lambda: bm.greedy_ids_from_features(f512, bench.CAPTION_LEN)
+elif which == "bahdanau_persistent":
+    bm = seeded(bah.ImageCaptioningModel(Pass(), bah.TransformerEncoderBlock(512, 512, 8, dropout=0.5),
+                                         bah.BahdanauDecoder(512, 512, 512, 256, bench.VOCAB, dropout=0.5)), 31)
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else bench.CAPTION_LEN
+    fn = lambda: bm.greedy_ids_from_features(f512, steps, mode="persistent", check=False)
 else:
     m = seeded(s2s.DecoderRNN(256, 512, bench.VOCAB, num_layers=2, rnn_type=which), 11)
     fn = lambda: m.sample_ids(f256, bench.CAPTION_LEN)

@@ -350,6 +350,9 @@ static int fz_check(const char* what, int NB, int H, int V, int steps) {
     if (NB > FZ_MAX_NB) { set_error("%s: NB=%d exceeds %d captions per call", what, NB, FZ_MAX_NB); return ICAP_ERR_LIMIT; }
     if (H % 4) { set_error("%s: H must be a multiple of 4", what); return ICAP_ERR_ALIGN; }
     if ((long long)NB * fz_blocks(V) > FZ_PART) { set_error("%s: NB x vocabulary blocks exceeds the staging buffer", what); return ICAP_ERR_LIMIT; }
+    // the two input vectors of every caption slot live in LDS beside 33 KB of static staging: 32 KB of them at most
+    const int nbt = NB <= 1 ? 1 : (NB <= 2 ? 2 : (NB <= 4 ? 4 : 8));
+    if (2LL * nbt * H * 4 > 32 * 1024) { set_error("%s: NB=%d captions of width H=%d exceed the kernel's LDS", what, NB, H); return ICAP_ERR_LIMIT; }
     return ICAP_OK;
 }
 

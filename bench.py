@@ -122,7 +122,13 @@ def linear_x3_work(sig):
     return 2.0 * M * K * Nn, 4.0 * M * K + 6.0 * K * Nn + 4.0 * M * Nn * (2 if has_res else 1)
 
 
-WORK = {"linear_f32x3": linear_x3_work, "linear_bf16": lambda s: linear_bf16_work(s), "conv2d_bf16": lambda s: conv_work(tuple(s[:10]) + (False,)), "stem_dwconv2d": stem_dw_work, "conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work, "expand_dwconv2d": expand_dw_work,
+def linear_thin_work(sig):
+    """(M, K, N, residual, gate): fp32 activations and weights."""
+    M, K, Nn, has_res = sig[:4]
+    return 2.0 * M * K * Nn, 4.0 * M * K + 4.0 * K * Nn + 4.0 * M * Nn * (2 if has_res else 1)
+
+
+WORK = {"linear_f32x3": linear_x3_work, "linear_thin": linear_thin_work, "linear_bf16": lambda s: linear_bf16_work(s), "conv2d_bf16": lambda s: conv_work(tuple(s[:10]) + (False,)), "stem_dwconv2d": stem_dw_work, "conv2d": conv_work, "dwconv2d": dw_work, "linear": linear_work, "expand_dwconv2d": expand_dw_work,
         # training-step launches: (flops, algorithmic bytes)
         "gemm_nn": gemm_work, "gemm_tn": gemm_work,
         "col_reduce": lambda s: (2.0 * s[1] * s[2], 4.0 * s[1] * s[2] * (2 if s[0] >= 2 else 1)),

@@ -119,6 +119,8 @@ SIGNATURES = {
     "icap_greedy_tfm_w16_f32": (_i, [C.POINTER(TfmWeights), _p, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_bah_w16_f32": (_i, [C.POINTER(BahWeights), _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "icap_greedy_bah_ws_floats": (_ll, [_i] * 5),
+    "icap_linear_thin_supported": (_i, [_i] * 2),
+    "icap_linear_thin_f32": (_i, [_p] * 6 + [_i, _p, _ll, _i, _i, _p]),
     "icap_greedy_bah_persist_max_nb": (_i, [_i] * 2),
     "icap_greedy_bah_persist_ws_bytes": (_ll, [_i] * 3),
     "icap_greedy_bah_persist_f32": (_i, [_p] * 10 + [_i] * 4 + [_p]),

@@ -35,6 +35,9 @@ int greedy_rnn2_fused_f32(int, const float*, const float*, const float*, const f
 int greedy_tfm_persist_max_nb(int, int, int);
 long long greedy_tfm_persist_ws_bytes(int, int, int, int);
 int greedy_tfm_persist_f32(const icap_tfm_weights*, const float*, const long long*, long long*, float*, void*, int, int, hipStream_t);
+int linear_thin_supported(int, int);
+int linear_thin_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, float*, long long, int, int,
+                    hipStream_t);
 int greedy_bah_persist_max_nb(int, int);
 long long greedy_bah_persist_ws_bytes(int, int, int);
 int greedy_bah_persist_f32(const float*, const float*, const float*, const float*, const float*, const float*, const long long*, long long*,
@@ -616,6 +619,12 @@ int icap_greedy_tfm_w16_f32(const icap_tfm_weights* w, const float* ca, const lo
 int icap_table_walk(const long long* next, const long long* start, long long* ids, const float* logits_tab, int ldl,
                     float* logits_out, int V, int B, int steps, void* stream) {
     return table_walk(next, start, ids, logits_tab, ldl, logits_out, V, B, steps, (hipStream_t)stream);
+}
+
+int icap_linear_thin_supported(int K, int N) { return linear_thin_supported(K, N); }
+int icap_linear_thin_f32(const float* x, const float* w, const float* scale, const float* bias, const float* residual, const float* gate,
+                         int hw, float* y, long long M, int K, int N, void* stream) {
+    return linear_thin_f32(x, w, scale, bias, residual, gate, hw, y, M, K, N, (hipStream_t)stream);
 }
 
 int icap_greedy_bah_persist_max_nb(int H, int V) { return greedy_bah_persist_max_nb(H, V); }

@@ -223,6 +223,17 @@ int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* s
  * (scale, bias, residual, gate [M/hw][K], activation; arg-max partials per 128-column tile:
  * icap_linear_bf16_argmax_parts(N) per row).  K % 8 == 0, N % 4 == 0.  cfg: -1 = by shape, 0 = 128x128, 1 = 64x128,
  * 2 = 64x64 tiles.  Replaces the same nn.Linear / 1x1 convolution sites as icap_conv2d_f32. */
+/* The thin 1x1 "projection" convolutions of the high-resolution MBConv blocks (transformer_word_level.py:13: EfficientNet-B0's
+ * _project_conv + _bn2 of blocks 0-2: 32 -> 16, 96 / 144 -> 24 channels over 3.2 - 12.8 M pixels at B = 1024) as a streaming
+ * kernel: y[M][N] = ((x[M][K] * gate[m / hw][k]) @ w[N][K]^T) * scale[n] + bias[n] (+ residual[m][n]) with the whole weight
+ * matrix resident in LDS, rows loaded straight into registers in the fp32 MFMA's operand layout, no barrier in the loop.
+ * Exact fp32 products (v_mfma_f32_32x32x2_f32).  icap_linear_thin_supported(K, N) = 1 for K in {32, 96, 144} with N <= 32,
+ * N % 4 == 0; gate (optional) needs hw >= 32; M < 2^31.  Same results as icap_conv2d_f32 on the same
+ * layer up to the order of the fp32 sums. */
+int icap_linear_thin_supported(int K, int N);
+int icap_linear_thin_f32(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                         const float* gate, int hw, float* y, long long M, int K, int N, void* stream);
+
 int icap_split3_f32(const float* src, unsigned short* dst, long long n, void* stream);
 int icap_linear_f32x3_f32(const void* x, int x_split, const unsigned short* w3, const float* scale, const float* bias,
                           const float* residual, const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg,

@@ -428,3 +428,33 @@ def test_layernorm_writes_its_result_split(rows, E):
     assert torch.equal(y3.view(torch.int16), ops.split3(y).view(torch.int16))
     back = y3[0].double() + y3[1].double() + y3[2].double()
     assert float((back - y.double()).abs().max()) <= 2e-7 * float(y.abs().max())
+
+
+@pytest.mark.parametrize("M,K,N,hw,use_res,use_gate", [
+    (3136 * 3, 32, 16, 3136, False, True), (784 * 5, 96, 24, 784, False, True), (784 * 4 + 0, 144, 24, 784, True, True),
+    (49 * 64 + 17, 144, 28, 49, False, True), (49 * 40, 96, 32, 49, True, True), (1000, 144, 32, 1, True, False),
+    (37, 32, 4, 37, False, True), (65, 144, 32, 1, False, False), (33 * 50, 96, 20, 33, True, True), (31, 32, 16, 1, True, False)])
+def test_linear_thin(M, K, N, hw, use_res, use_gate):
+    """The streaming kernel of the thin projection layers against a float64 product: every (K, width) instantiation, gate
+    rows that change inside a 32-row block (hw not a multiple of 32), ragged last block, residual."""
+    from image_captioning_amd import ops
+    d = dev()
+    if use_gate and M % hw:
+        M = M // hw * hw
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    scale = torch.rand(N, generator=torch.Generator().manual_seed(4)) + 0.5
+    res = rnd(M, N, seed=5) if use_res else None
+    gate = torch.rand(M // hw, K, generator=torch.Generator().manual_seed(6)) if use_gate else None
+    xg = x * gate.repeat_interleave(hw, 0) if use_gate else x
+    assert ops.linear_thin_supported(K, N)
+    got = ops.linear_thin(x.to(d), w.to(d), b.to(d), scale.to(d), residual=res.to(d) if use_res else None,
+                          gate=gate.to(d) if use_gate else None, hw=hw).cpu().double()
+    ref = (xg.double() @ w.double().t()) * scale.double() + b.double()
+    if use_res:
+        ref = ref + res.double()
+    f32 = ops.linear(xg.to(d), w.to(d), b.to(d), scale.to(d), residual=res.to(d) if use_res else None).cpu().double()
+    err, err32 = (got - ref).abs().max().item(), (f32 - ref).abs().max().item()
+    assert err <= max(4 * err32, 2e-6 * ref.abs().max().item()), (err, err32)
+    assert not ops.linear_thin_supported(64, 16) and not ops.linear_thin_supported(32, 40) and not ops.linear_thin_supported(240, 40)
+    with pytest.raises(ops.IcapError):
+        ops.linear_thin(torch.zeros(64, 64, device=d), torch.zeros(16, 64, device=d))

@@ -36,6 +36,7 @@ int greedy_tfm_persist_max_nb(int, int, int);
 long long greedy_tfm_persist_ws_bytes(int, int, int, int);
 int greedy_tfm_persist_f32(const icap_tfm_weights*, const float*, const long long*, long long*, float*, void*, int, int, hipStream_t);
 int linear_thin_supported(int, int);
+int linear_f32x3_tall_supported(int, int, int, int);
 int linear_thin_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, float*, long long, int, int,
                     hipStream_t);
 int greedy_bah_persist_max_nb(int, int);
@@ -622,6 +623,7 @@ int icap_table_walk(const long long* next, const long long* start, long long* id
 }
 
 int icap_linear_thin_supported(int K, int N) { return linear_thin_supported(K, N); }
+int icap_linear_f32x3_tall_supported(int K, int N, int hw, int gated) { return linear_f32x3_tall_supported(K, N, hw, gated); }
 int icap_linear_thin_f32(const float* x, const float* w, const float* scale, const float* bias, const float* residual, const float* gate,
                          int hw, float* y, long long M, int K, int N, void* stream) {
     return linear_thin_f32(x, w, scale, bias, residual, gate, hw, y, M, K, N, (hipStream_t)stream);

@@ -658,13 +658,23 @@ static int split_args_ok(const char* what, const float* x, const unsigned short*
     return ICAP_OK;
 }
 
-// cfg: -1 = choose by shape, 0 = 128x128, 1 = 64x128, 2 = 64x64 tiles
+// the tall-activation kernel (gemm_x3t.hip)
+int linear_f32x3_tall_supported(int K, int N, int hw, int gated);
+int linear_f32x3_tall_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
+                          const float* gate, int hw, float* y, int M, int K, int N, hipStream_t st);
+
+// cfg: -1 = choose by shape, 0 = 128x128, 1 = 64x128, 2 = 64x64 tiles, 3 = the tall-activation kernel (activations held in
+// registers for the whole contraction; fp32 x, no activation function, K a multiple of 48: linear_f32x3_tall_supported)
 int linear_f32x3_f32(const float* x, int x_split, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
                      const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg, hipStream_t st) {
     if (!y || (gate && hw <= 0) || (gate && x_split)) { set_error("linear_f32x3: bad arguments (pre-split activations take no gate)"); return ICAP_ERR_ARG; }
     if (x_split && (((size_t)M * K * 2) & 15)) { set_error("linear_f32x3: every activation plane must be 16-byte aligned"); return ICAP_ERR_ALIGN; }
     const int rc = split_args_ok("linear_f32x3", x, w3, scale, bias, residual, gate, y, M, K, N);
     if (rc != ICAP_OK) return rc;
+    if (cfg == 3) {
+        if (x_split || act != ACT_NONE) { set_error("linear_f32x3: the tall form takes fp32 activations and no activation function"); return ICAP_ERR_ARG; }
+        return linear_f32x3_tall_f32(x, w3, scale, bias, residual, gate, hw, y, M, K, N, st);
+    }
     GemmBf16Params p{x, w3, scale, bias, residual, gate, y, M, N, K, gate ? hw : 1, act, 0, nullptr, nullptr};
     if (cfg < 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);

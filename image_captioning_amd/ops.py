@@ -114,8 +114,13 @@ _x3_choice: dict = {}
 _X3_FP32 = -2
 
 
-def _x3_pick(M, K, Nn, run_fp32, run_split):
-    key = (M, K, Nn)
+def linear_f32x3_tall_supported(K: int, Nn: int, hw: int = 1, gated: bool = False) -> bool:
+    return bool(N.load().icap_linear_f32x3_tall_supported(K, Nn, hw, int(gated)))
+
+
+def _x3_pick(M, K, Nn, run_fp32, run_split, tall=False):
+    """tall: the layer can also run on the tall-activation kernel (cfg 3), which only the tuner picks."""
+    key = (M, K, Nn, tall)
     c = _x3_choice.get(key)
     if c is not None:
         return c
@@ -125,7 +130,7 @@ def _x3_pick(M, K, Nn, run_fp32, run_split):
         tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
         return -1 if (K >= X3_MIN_K and tiles >= X3_MIN_TILES) else _X3_FP32
     best, best_ms = _X3_FP32, None
-    for cand in (_X3_FP32, 0, 1, 2):
+    for cand in (_X3_FP32, 0, 1, 2) + ((3,) if tall else ()):
         fn = run_fp32 if cand == _X3_FP32 else (lambda c=cand: run_split(c))
         for _ in range(2):
             fn()
@@ -170,6 +175,12 @@ def linear_thin(x, w, bias=None, scale=None, residual=None, gate=None, hw=1, out
     return out
 
 
+# "f32x3" mode: layers without an activation function (the projection convolutions) of at least this many rows also offer the
+# tuner the tall-activation kernel (linear_f32x3 cfg 3).
+TALL_PROJECT = True
+TALL_MIN_ROWS = 16384
+
+
 def linear_x3_auto(x, w, w3_cache: dict, key, bias=None, scale=None, act=ACT_NONE, residual=None, gate=None, hw=1):
     """One Linear / 1x1-convolution layer in "f32x3" mode: the split-product kernel or the fp32 kernel, whichever
     _x3_pick says; the weight's three bf16 planes are made on first use and kept in w3_cache[key]."""
@@ -190,7 +201,8 @@ def linear_x3_auto(x, w, w3_cache: dict, key, bias=None, scale=None, act=ACT_NON
     def run_split(cfg):
         return linear_f32x3(x, w3(), bias, scale, act=act, residual=residual, gate=gate, hw=hw, cfg=cfg)
 
-    c = _x3_pick(M, K, Nn, run_fp32, run_split)
+    tall = TALL_PROJECT and act == ACT_NONE and M >= TALL_MIN_ROWS and linear_f32x3_tall_supported(K, Nn, hw, gate is not None)
+    c = _x3_pick(M, K, Nn, run_fp32, run_split, tall)
     return run_fp32() if c == _X3_FP32 else run_split(c)
 
 

@@ -212,17 +212,6 @@ int icap_linear_bf16_f32(const void* x, int x_bf16, const unsigned short* w_bf16
                          void* stream);
 int icap_to_bf16_f32(const float* src, unsigned short* dst, long long n, void* stream);
 
-/* fp32-ACCURATE linear layers on the bf16 matrix cores (the fp32 MFMA retires 1/16 of the bf16 MFMA's flops per cycle).
- * Every fp32 operand is the exact sum of three bf16 values (hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid));
- * the six products hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi are exact in the MFMA's fp32 accumulation and the three
- * dropped ones are each <= 2^-24 of the product, so the result differs from an fp32 dot product by a few units of fp32
- * rounding.  icap_split3_f32 prepares the weights once: src fp32 [n] -> dst bf16 [3][n] (n even).  The activations x stay
- * fp32 in memory and are split while they are staged (x_split = 0), or arrive as the three planes [3][M][K] icap_split3_f32
- * makes of them (x_split = 1, no gate): worth it when the result has many column tiles, each of which would repeat the
- * split arithmetic (the decoder's vocabulary projection: 53).  Same epilogue as icap_conv2d_f32 / icap_linear_argmax_f32
- * (scale, bias, residual, gate [M/hw][K], activation; arg-max partials per 128-column tile:
- * icap_linear_bf16_argmax_parts(N) per row).  K % 8 == 0, N % 4 == 0.  cfg: -1 = by shape, 0 = 128x128, 1 = 64x128,
- * 2 = 64x64 tiles.  Replaces the same nn.Linear / 1x1 convolution sites as icap_conv2d_f32. */
 /* The thin 1x1 "projection" convolutions of the high-resolution MBConv blocks (transformer_word_level.py:13: EfficientNet-B0's
  * _project_conv + _bn2 of blocks 0-2: 32 -> 16, 96 / 144 -> 24 channels over 3.2 - 12.8 M pixels at B = 1024) as a streaming
  * kernel: y[M][N] = ((x[M][K] * gate[m / hw][k]) @ w[N][K]^T) * scale[n] + bias[n] (+ residual[m][n]) with the whole weight
@@ -234,7 +223,22 @@ int icap_linear_thin_supported(int K, int N);
 int icap_linear_thin_f32(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
                          const float* gate, int hw, float* y, long long M, int K, int N, void* stream);
 
+/* fp32-ACCURATE linear layers on the bf16 matrix cores (the fp32 MFMA retires 1/16 of the bf16 MFMA's flops per cycle).
+ * Every fp32 operand is the exact sum of three bf16 values (hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid));
+ * the six products hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi are exact in the MFMA's fp32 accumulation and the three
+ * dropped ones are each <= 2^-24 of the product, so the result differs from an fp32 dot product by a few units of fp32
+ * rounding.  icap_split3_f32 prepares the weights once: src fp32 [n] -> dst bf16 [3][n] (n even).  The activations x stay
+ * fp32 in memory and are split while they are staged (x_split = 0), or arrive as the three planes [3][M][K] icap_split3_f32
+ * makes of them (x_split = 1, no gate): worth it when the result has many column tiles, each of which would repeat the
+ * split arithmetic (the decoder's vocabulary projection: 53).  Same epilogue as icap_conv2d_f32 / icap_linear_argmax_f32
+ * (scale, bias, residual, gate [M/hw][K], activation; arg-max partials per 128-column tile:
+ * icap_linear_bf16_argmax_parts(N) per row).  K % 8 == 0, N % 4 == 0.  cfg: -1 = by shape, 0 = 128x128, 1 = 64x128,
+ * 2 = 64x64 tiles, 3 = the kernel for tall activations (the gated 14 x 14 / 7 x 7 projection convolutions: a wave keeps
+ * its 32 rows in registers for the whole contraction, split there, and only the weights pass through LDS; fp32 x, no
+ * activation function, shapes for which icap_linear_f32x3_tall_supported(K, N, hw, gated) = 1: K a multiple of 48, gated
+ * images of at least 43 pixels).  Replaces the same nn.Linear / 1x1 convolution sites as icap_conv2d_f32. */
 int icap_split3_f32(const float* src, unsigned short* dst, long long n, void* stream);
+int icap_linear_f32x3_tall_supported(int K, int N, int hw, int gated);
 int icap_linear_f32x3_f32(const void* x, int x_split, const unsigned short* w3, const float* scale, const float* bias,
                           const float* residual, const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg,
                           void* stream);

@@ -458,3 +458,34 @@ def test_linear_thin(M, K, N, hw, use_res, use_gate):
     assert not ops.linear_thin_supported(64, 16) and not ops.linear_thin_supported(32, 40) and not ops.linear_thin_supported(240, 40)
     with pytest.raises(ops.IcapError):
         ops.linear_thin(torch.zeros(64, 64, device=d), torch.zeros(16, 64, device=d))
+
+
+@pytest.mark.parametrize("M,K,N,hw,use_res,use_gate", [
+    (196 * 7, 480, 80, 196, True, True), (196 * 5 + 0, 672, 112, 196, True, True), (196 * 3, 240, 80, 196, False, True),
+    (49 * 30, 1152, 192, 49, True, True), (49 * 11, 1152, 320, 49, False, True), (49 * 9, 672, 192, 49, False, True),
+    (1000, 96, 24, 1, True, False), (129, 48, 4, 1, False, False), (127, 192, 36, 127, False, True), (43 * 12, 144, 200, 43, True, True)])
+def test_linear_f32x3_tall(M, K, N, hw, use_res, use_gate):
+    """cfg 3 of the split-product layer (activations kept in registers over the whole contraction) against a float64 product
+    and against the tiled split-product kernel: 48- and 96-wide chunks, one to six column blocks and two column tiles, images
+    that change inside a tile (hw = 49, 43), ragged last tile, residual."""
+    from image_captioning_amd import ops
+    d = dev()
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    scale = torch.rand(N, generator=torch.Generator().manual_seed(4)) + 0.5
+    res = rnd(M, N, seed=5) if use_res else None
+    gate = torch.rand(M // hw, K, generator=torch.Generator().manual_seed(6)) if use_gate else None
+    xg = x * gate.repeat_interleave(hw, 0) if use_gate else x
+    assert ops.linear_f32x3_tall_supported(K, N, hw, use_gate)
+    w3 = ops.split3(w.to(d))
+    kw = dict(residual=res.to(d) if use_res else None, gate=gate.to(d) if use_gate else None, hw=hw)
+    got = ops.linear_f32x3(x.to(d), w3, b.to(d), scale.to(d), cfg=3, **kw).cpu().double()
+    tiled = ops.linear_f32x3(x.to(d), w3, b.to(d), scale.to(d), cfg=2, **kw).cpu().double()
+    ref = (xg.double() @ w.double().t()) * scale.double() + b.double()
+    if use_res:
+        ref = ref + res.double()
+    err, err_t = (got - ref).abs().max().item(), (tiled - ref).abs().max().item()
+    assert err <= max(4 * err_t, 2e-6 * ref.abs().max().item()), (err, err_t)
+    assert not ops.linear_f32x3_tall_supported(100, 16) and not ops.linear_f32x3_tall_supported(96, 18)
+    assert not ops.linear_f32x3_tall_supported(96, 16, 36, True)
+    with pytest.raises(ops.IcapError):
+        ops.linear_f32x3(torch.zeros(64, 64, device=d), ops.split3(torch.zeros(16, 64, device=d)), cfg=3)

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3t_kernel(const X3tParams p) {
     constexpr int WU = CK / 8;                // 16-byte units per weight row
     constexpr int NWL = (WROWS * WU + 255) / 256;   // 16-byte units of the weight chunk per thread
     constexpr int EP_LD = NP + 4;
-    static_assert(WROWS * WPITCH * 2 + XT_GI * CK * 4 + 4 * 32 * XT_XP * 4 >= 64 * EP_LD * 4, "the result tile (two passes of 64 rows) fits");
+    static_assert(WROWS * WPITCH * 2 + XT_GI * CK * 4 + 4 * 32 * XT_XP * 4 >= 128 * EP_LD * 4, "the result tile fits the staging buffers");
     extern __shared__ __attribute__((aligned(16))) unsigned char xt_smem[];
     unsigned short* wl = reinterpret_cast<unsigned short*>(xt_smem);                 // [3][NP][WPITCH]
     float* gl = reinterpret_cast<float*>(xt_smem + WROWS * WPITCH * 2);               // [XT_GI][CK] this chunk of the tile's gate rows
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3t_kernel(const X3tParams p) {
     }
     const float* xf = xw + lr * XT_XP + lh * HC;         // this lane's fragment source
     // ---- gate rows: lane (r, h) multiplies by its row's image; thread t < XT_GI CK / 4 stages one 16-byte piece per chunk
-    const bool gated = p.gate != nullptr;
+    const bool gated = p.gate != nullptr;      // ungated: the staged gate rows stay at 1
     const int img0 = gated ? m0 / p.hw : 0;
     const float* gf = gl + (gated ? (min(m0 + wave * 32 + lr, p.M - 1) / p.hw - img0) * CK : 0) + lh * HC;
     const float* g_src = nullptr;
@@ -144,16 +144,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3t_kernel(const X3tParams p) {
         store_chunk();
         load_chunk(min(c + 1, nchunk - 1));
         __syncthreads();
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            // this K step's eight activations: gate, exact three-way split
+        // One basic block per chunk (no branch on the gate: ungated layers multiply by the ones the staging threads keep in the
+        // gate rows), written as a software pipeline: the gate multiply and the exact three-way split of K step g + 1 are
+        // independent of the matrix instructions of step g, so the scheduler can run them underneath.
+        xt_bf16x8 af[3];
+        auto split_step = [&](int g, xt_bf16x8 (&out)[3]) __attribute__((always_inline)) {
             const xt_f32x4 a0 = *reinterpret_cast<const xt_f32x4*>(xf + 8 * g), a1 = *reinterpret_cast<const xt_f32x4*>(xf + 8 * g + 4);
-            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            if (gated) {
-                const xt_f32x4 g0 = *reinterpret_cast<const xt_f32x4*>(gf + 8 * g), g1 = *reinterpret_cast<const xt_f32x4*>(gf + 8 * g + 4);
-                v[0] *= g0[0]; v[1] *= g0[1]; v[2] *= g0[2]; v[3] *= g0[3];
-                v[4] *= g1[0]; v[5] *= g1[1]; v[6] *= g1[2]; v[7] *= g1[3];
-            }
+            const xt_f32x4 g0 = *reinterpret_cast<const xt_f32x4*>(gf + 8 * g), g1 = *reinterpret_cast<const xt_f32x4*>(gf + 8 * g + 4);
+            const float v[8] = {a0[0] * g0[0], a0[1] * g0[1], a0[2] * g0[2], a0[3] * g0[3], a1[0] * g1[0], a1[1] * g1[1], a1[2] * g1[2], a1[3] * g1[3]};
             unsigned hi[4], mid[4], lo[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -162,10 +160,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3t_kernel(const X3tParams p) {
                 mid[e] = xt_pack(r0, r1);
                 lo[e] = xt_pack(r0 - __uint_as_float(mid[e] << 16), r1 - __uint_as_float(mid[e] & 0xffff0000u));
             }
-            xt_bf16x8 af[3];
-            af[0] = __builtin_bit_cast(xt_bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
-            af[1] = __builtin_bit_cast(xt_bf16x8, make_uint4(mid[0], mid[1], mid[2], mid[3]));
-            af[2] = __builtin_bit_cast(xt_bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+            out[0] = __builtin_bit_cast(xt_bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+            out[1] = __builtin_bit_cast(xt_bf16x8, make_uint4(mid[0], mid[1], mid[2], mid[3]));
+            out[2] = __builtin_bit_cast(xt_bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+        };
+        split_step(0, af);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
             // B fragments: lane (n, h) needs the same eight k of row n of each plane
             xt_bf16x8 bf[3][RN];
 #pragma unroll
@@ -173,51 +174,47 @@ __global__ __launch_bounds__(256, 2) void gemm_x3t_kernel(const X3tParams p) {
 #pragma unroll
                 for (int j = 0; j < RN; ++j)
                     bf[pl][j] = *reinterpret_cast<const xt_bf16x8*>(wl + (pl * NP + j * 32 + lr) * WPITCH + lh * HC + 8 * g);
+            xt_bf16x8 an[3] = {af[0], af[1], af[2]};
+            if (g + 1 < NG) split_step(g + 1, an);
             // smallest terms first; consecutive MFMAs go to different accumulators
             constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
                 for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa[q]], bf[pb[q]][j], acc[j], 0, 0, 0);
+            af[0] = an[0]; af[1] = an[1]; af[2] = an[2];
         }
     }
     __syncthreads();                           // the staging buffers become the result tile
 
-    // ---- epilogue: accumulators -> LDS (row-major, 64 rows per pass) -> 16-byte stores along the output row
-    constexpr int BN4 = NP / 4;
-    constexpr int EP_RPI = 256 / BN4;
-    const int en4 = tid % BN4, erow = tid / BN4;
-    const int n = n0 + en4 * 4;
-    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < p.N) {
-        if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
-        if (p.bias) bi4 = *reinterpret_cast<const float4*>(p.bias + n);
+    // ---- epilogue, every wave on its own: its 32 x NP accumulator block -> a wave-private LDS image (row-major) -> 16-byte
+    // pieces along the output rows; the residual pieces are requested before the image is written, and no barrier is needed
+    constexpr int BN4 = NP / 4;                        // 16-byte pieces per tile row
+    constexpr int NPC = (32 * BN4 + 63) / 64;          // pieces per lane
+    float* ew = ep + wave * 32 * EP_LD;
+    const int mw = m0 + wave * 32;
+    xt_f32x4 rv[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const int q = lane + 64 * i, row = q / BN4, n = n0 + 4 * (q - row * BN4);
+        rv[i] = xt_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.residual && row < 32 && mw + row < p.M && n < p.N) rv[i] = *reinterpret_cast<const xt_f32x4*>(p.residual + (size_t)(mw + row) * p.N + n);
     }
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if ((wave >> 1) == pass) {
+    for (int j = 0; j < RN; ++j)
 #pragma unroll
-            for (int j = 0; j < RN; ++j)
+        for (int e = 0; e < 16; ++e) ew[((e & 3) + 8 * (e >> 2) + 4 * lh) * EP_LD + j * 32 + lr] = acc[j][e];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) ep[((wave & 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * EP_LD + j * 32 + lr] = acc[j][e];
-        }
-        __syncthreads();
-        if (erow < EP_RPI && n < p.N) {
-            for (int row = erow; row < 64; row += EP_RPI) {
-                const int m = m0 + pass * 64 + row;
-                if (m >= p.M) break;
-                float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
-                v.x = fmaf(v.x, sc4.x, bi4.x); v.y = fmaf(v.y, sc4.y, bi4.y);
-                v.z = fmaf(v.z, sc4.z, bi4.z); v.w = fmaf(v.w, sc4.w, bi4.w);
-                const size_t o = (size_t)m * p.N + n;
-                if (p.residual) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + o);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                }
-                *reinterpret_cast<float4*>(p.y + o) = v;
-            }
-        }
-        __syncthreads();
+    for (int i = 0; i < NPC; ++i) {
+        const int q = lane + 64 * i, row = q / BN4, c4 = q - row * BN4, n = n0 + 4 * c4;
+        if (row >= 32 || mw + row >= p.M || n >= p.N) continue;
+        xt_f32x4 v = *reinterpret_cast<const xt_f32x4*>(ew + row * EP_LD + 4 * c4);
+        xt_f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const xt_f32x4*>(p.scale + n);
+        if (p.bias) bi = *reinterpret_cast<const xt_f32x4*>(p.bias + n);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaf(v[t], sc[t], bi[t]) + rv[i][t];
+        *reinterpret_cast<xt_f32x4*>(p.y + (size_t)(mw + row) * p.N + n) = v;
     }
 }
 

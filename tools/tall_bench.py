@@ -20,10 +20,13 @@ def timeit(fn, reps=20):
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""          # substring of the layer names to run
 shapes = [("28 240->40", 784, 240, 40, True), ("14 240->80", 196, 240, 80, False), ("14 480->80", 196, 480, 80, True),
           ("14 480->112", 196, 480, 112, False), ("14 672->112", 196, 672, 112, True), ("7 672->192", 49, 672, 192, False),
           ("7 1152->192", 49, 1152, 192, True), ("7 1152->320", 49, 1152, 320, False)]
 for name, hw, K, N, use_res in shapes:
+    if ONLY not in name:
+        continue
     M = B * hw
     x = torch.randn(M, K, device=d)
     w = torch.randn(N, K, device=d) * K ** -0.5

@@ -112,6 +112,7 @@ X3_MIN_K = 160
 X3_MIN_TILES = 128
 _x3_choice: dict = {}
 _X3_FP32 = -2
+_X3_USE_TUNED = True         # False inside `with untuned()`: the remembered choices are ignored, as conv2d's are
 
 
 def linear_f32x3_tall_supported(K: int, Nn: int, hw: int = 1, gated: bool = False) -> bool:
@@ -121,7 +122,7 @@ def linear_f32x3_tall_supported(K: int, Nn: int, hw: int = 1, gated: bool = Fals
 def _x3_pick(M, K, Nn, run_fp32, run_split, tall=False):
     """tall: the layer can also run on the tall-activation kernel (cfg 3), which only the tuner picks."""
     key = (M, K, Nn, tall)
-    c = _x3_choice.get(key)
+    c = _x3_choice.get(key) if _X3_USE_TUNED else None
     if c is not None:
         return c
     if K % 8 or Nn % 4:
@@ -363,16 +364,17 @@ class untuned:
     remembered (verification reruns)."""
 
     def __enter__(self):
-        global AUTOTUNE, THIN_PROJECT
-        self.prev, self.tune, self.thin = N.load().icap_conv2d_use_tuned(0), AUTOTUNE, THIN_PROJECT
+        global AUTOTUNE, THIN_PROJECT, _X3_USE_TUNED
+        self.prev, self.tune, self.thin, self.x3 = N.load().icap_conv2d_use_tuned(0), AUTOTUNE, THIN_PROJECT, _X3_USE_TUNED
         AUTOTUNE = False
         THIN_PROJECT = False         # the rerun goes through the general implicit-GEMM kernel, not the specialised streaming one
+        _X3_USE_TUNED = False        # and the split-product layers on the shape rule, never on a remembered (tall) configuration
         return self
 
     def __exit__(self, *exc):
-        global AUTOTUNE, THIN_PROJECT
+        global AUTOTUNE, THIN_PROJECT, _X3_USE_TUNED
         N.load().icap_conv2d_use_tuned(self.prev)
-        AUTOTUNE, THIN_PROJECT = self.tune, self.thin
+        AUTOTUNE, THIN_PROJECT, _X3_USE_TUNED = self.tune, self.thin, self.x3
         return False
 
 

@@ -539,8 +539,15 @@ int linear_bf16_f32(const void* xv, int x_bf16, const unsigned short* w, const f
 // KH x KW convolution, NHWC fp32 image, bf16 weights [Cout][KH][KW][Cin] (Cin % 32 == 0; or Cin == 4 with every weight
 // row zero-padded from KH*KW*4 to a multiple of 32 values), fused scale / bias / residual / activation: the dense layers
 // of the ResNet-18 and VGG-16 encoders in bf16 compute mode.
-// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256, 4 = 256x128 tiles.
+// cfg: -1 = choose by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256, 4 = 256x128 tiles, 5 = the 256-row eight-wave
+// kernel with direct-to-LDS loads (conv_bf16_wide.hip: bf16 x and y, bf16 or no residual, Cin % 64 == 0, Cout % 8 == 0).
 // io_bf16: bit 0 = x is bf16 (Cin % 32 == 0 only), bit 1 = y is stored as bf16, bit 2 = residual is bf16.
+int conv2d_bf16_wide_supported(int Cin, int Cout);
+int conv2d_bf16_wide(const unsigned short* x, const unsigned short* w, const float* scale, const float* bias, const unsigned short* residual,
+                     unsigned short* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
+                     int Wo, int act, hipStream_t st);
+constexpr long long CONV_WIDE_MIN_TILES = 192;   // 256-row tiles below which the narrower tile kernels fill the chip better
+
 int conv2d_bf16_f32(const void* xv, const unsigned short* w, const float* scale, const float* bias, const void* resv, void* yv,
                     int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
                     int io_bf16, int cfg, hipStream_t st) {
@@ -572,6 +579,16 @@ int conv2d_bf16_f32(const void* xv, const unsigned short* w, const float* scale,
     if (M > 0x7fffffffLL || K > 0x7fffffffLL || M * Cout > (1LL << 40) || ((M + 63) / 64) * ((Cout + 63) / 64) > 0x7fffffffLL) {
         set_error("conv2d_bf16: problem too large");
         return ICAP_ERR_LIMIT;
+    }
+    const bool wide_ok = x16 && (io_bf16 & 2) && (!residual || (io_bf16 & 4)) && conv2d_bf16_wide_supported(Cin, Cout);
+    if (cfg < 0 && wide_ok) {
+        const int bn = Cout > 128 ? 256 : (Cout > 64 ? 128 : 64);
+        if (((M + 255) / 256) * ((Cout + bn - 1) / bn) >= CONV_WIDE_MIN_TILES && K >= 256) cfg = 5;    // at least four K tiles to pipeline
+    }
+    if (cfg == 5) {
+        if (!wide_ok) { set_error("conv2d_bf16: the wide form takes bf16 x / y / residual, Cin %% 64 == 0, Cout %% 8 == 0"); return ICAP_ERR_ARG; }
+        return conv2d_bf16_wide(reinterpret_cast<const unsigned short*>(xv), w, scale, bias, reinterpret_cast<const unsigned short*>(resv),
+                                reinterpret_cast<unsigned short*>(yv), B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, st);
     }
     GemmBf16Params p{x, w, scale, bias, residual, nullptr, y, (int)M, Cout, (int)K, 1, act, 0, nullptr, nullptr,
                      H, W, Cin, KW, stride, pad_t, pad_l, Ho, Wo, KH * KW, (io_bf16 >> 1) & 1, (io_bf16 >> 2) & 1};

@@ -234,7 +234,7 @@ def pointwise_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=N
 
 
 def dense_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None, *, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE,
-               out_bf16=False):
+               out_bf16=False, cfg=-1):
     """KH x KW convolution (conv2d's arguments): the fp32 implicit-GEMM kernel, or - in bf16 compute mode and for
     Cin % 32 == 0 (or the 4-channel padded image), Cout % 4 == 0 - icap_conv2d_bf16_f32 with a cached bf16 copy of the
     weight.  In that mode x and residual may be bf16 tensors and out_bf16 asks for a bf16 result (activations kept in
@@ -266,7 +266,7 @@ def dense_conv(x, w, w16_cache: dict, key, scale=None, bias=None, residual=None,
     N.check(N.load().icap_conv2d_bf16_f32(_ck(x, "x", x.dtype if x16 else torch.float32), _ck(w16, "w", torch.bfloat16), _ck(scale, "scale"),
                                           _ck(bias, "bias"), _ck(residual, "residual", torch.bfloat16 if r16 else torch.float32),
                                           _ck(out, "out", out.dtype), B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo, act,
-                                          int(x16) | (int(bool(out_bf16)) << 1) | (int(r16) << 2), -1, _stream()), "conv2d_bf16")
+                                          int(x16) | (int(bool(out_bf16)) << 1) | (int(r16) << 2), cfg, _stream()), "conv2d_bf16")
     span.done()
     return out
 

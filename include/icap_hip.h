@@ -263,7 +263,10 @@ int icap_linear_x3dl_argmax_f32(const unsigned short* x3, const unsigned short* 
  * y = act(conv * scale + bias (+ residual)) [B][Ho][Wo][Cout]; taps outside the image are zeros (pad_t / pad_l; bottom /
  * right padding follows from Ho / Wo).  Tensors are fp32 unless io_bf16 says otherwise: bit 0 = x is bf16 (Cin % 32 == 0
  * only), bit 1 = y is stored as bf16 (round to nearest even), bit 2 = residual is bf16 - activations kept in bf16 from
- * one layer to the next.  cfg: -1 = by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256, 4 = 256x128 tiles. */
+ * one layer to the next.  cfg: -1 = by shape, 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x256, 4 = 256x128 tiles of the
+ * four-wave kernel; 5 = the eight-wave kernel on 256-row tiles whose operands go global -> LDS directly (bf16 x and y, bf16
+ * or no residual, Cin % 64 == 0, Cout % 8 == 0 - anything else is an argument error; cfg -1 picks it for such layers from
+ * 192 tiles and four 64-deep K tiles up). */
 int icap_conv2d_bf16_f32(const void* x, const unsigned short* w_bf16, const float* scale, const float* bias, const void* residual,
                          void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
                          int Wo, int act, int io_bf16, int cfg, void* stream);

@@ -299,6 +299,35 @@ def test_dense_conv_bf16_storage(bf16_mode, B, H, W, Cin, Cout, K, stride, res):
         ops.dense_conv(x16, w, {}, "k", sc, bi, stride=stride, pad=pad)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,stride,res", [
+    (2, 14, 14, 64, 64, 3, 1, True), (3, 9, 11, 64, 160, 3, 2, False), (1, 7, 7, 512, 512, 3, 1, True), (2, 28, 28, 128, 256, 1, 2, False),
+    (5, 16, 16, 128, 128, 3, 1, False), (1, 30, 23, 64, 72, 3, 1, True), (2, 12, 12, 192, 264, 3, 1, False), (1, 3, 3, 64, 8, 3, 1, False)])
+def test_dense_conv_bf16_wide(bf16_mode, B, H, W, Cin, Cout, K, stride, res):
+    """cfg 5 of icap_conv2d_bf16_f32 (256-row tiles, eight waves, direct-to-LDS loads, bf16 in and out) against the tile kernel on
+    the same bf16 tensors: every tile width, ragged last row / column tile, stride 2, 1x1, residual; sums in another order, so
+    the bf16 results may differ by one rounding of values whose fp32 sums differ in the last bits."""
+    ops = bf16_mode
+    ops.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(B * 10 + Cin + Cout)
+    pad = (K // 2,) * 4
+    x16 = torch.randn(B, H, W, Cin, generator=g).to(D).to(torch.bfloat16)
+    w = (torch.randn(Cout, K, K, Cin, generator=g) * (Cin * K * K) ** -0.5).to(D)
+    sc, bi = (torch.rand(Cout, generator=g) + 0.5).to(D), (torch.randn(Cout, generator=g) * 0.1).to(D)
+    Ho, Wo = ops.conv_out_size(H, K, stride, pad[0], pad[1]), ops.conv_out_size(W, K, stride, pad[2], pad[3])
+    r16 = torch.randn(B, Ho, Wo, Cout, generator=g).to(D).to(torch.bfloat16) if res else None
+    cache = {}
+    for act in (ops.ACT_RELU, ops.ACT_NONE):
+        ref32 = ops.dense_conv(x16, w, cache, "k", sc, bi, residual=r16, stride=stride, pad=pad, act=act, cfg=2)
+        y = ops.dense_conv(x16, w, cache, "k", sc, bi, residual=r16, stride=stride, pad=pad, act=act, out_bf16=True, cfg=5)
+        assert y.dtype == torch.bfloat16 and tuple(y.shape) == (B, Ho, Wo, Cout)
+        err = (y.float() - ref32).abs()
+        tol = 2.0 ** -8 * ref32.abs() + 1e-5 * float(ref32.abs().max())       # one bf16 rounding (half an ulp = 2^-9 relative) and change
+        assert bool((err <= tol).all()), float((err - tol).max())
+        assert float((y.float() - ref32.to(torch.bfloat16).float()).abs().max()) <= 2.0 ** -7 * float(ref32.abs().max())
+    with pytest.raises(ops.IcapError):       # fp32 tensors, or channels that are not whole K tiles, are an error for this configuration
+        ops.dense_conv(x16.float(), w, cache, "k", sc, bi, stride=stride, pad=pad, cfg=5)
+
+
 def test_pooling_of_bf16_activations(bf16_mode):
     import torch.nn.functional as F
     ops = bf16_mode

@@ -325,15 +325,18 @@ class EfficientNetB0(nn.Module):
         """[B,3,H,W] NCHW -> [B,1280] (stem, 16 MBConv blocks, head, global average pool)."""
         require_eval(self, "EfficientNet-B0")
         p = self._prep.get(self, self._build)
-        x = ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)
         lo, hi = same_pad(3, 2)
         blocks = p["blocks"]
         d0 = blocks[0]
-        if d0["expand"] is None and d0["k"] == 3 and d0["stride"] == 1 and not d0["skip"]:
+        fused_stem = d0["expand"] is None and d0["k"] == 3 and d0["stride"] == 1 and not d0["skip"]
+        # the fused stem kernel reads the planar image as it comes (fp32 modes); every other path takes it interleaved and padded
+        planar = fused_stem and ops.COMPUTE_DTYPE != "bf16" and ops.STEM_NCHW
+        x = images.float().contiguous() if planar else ops.nchw_to_nhwc_pad(images.float().contiguous(), 4)
+        if fused_stem:
             # the stem's 112x112x32 output feeds only block 0's depthwise convolution: both run in one kernel
             # (in bf16 mode the fused kernels hand their result to the project convolution as a bf16 tensor)
             h, part = ops.stem_dwconv2d(x, p["stem_w"], *p["stem_sb"], d0["dw_w"], *d0["dw_sb"], stem_pad=(lo, hi, lo, hi),
-                                        pad=(1, 1, 1, 1), want_partial=True,
+                                        pad=(1, 1, 1, 1), want_partial=True, nchw=planar,
                                         out_bf16=ops.bf16_activations_ok(d0["dw_w"].shape[1], d0["proj"][0].shape[0]))
             gate = ops.se_gate(part, h.shape[1] * h.shape[2], *d0["se"])
             x = ops.pointwise_conv(h, d0["proj"][0], d0, "proj16", *d0["proj"][1], gate=gate)

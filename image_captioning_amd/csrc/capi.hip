@@ -330,6 +330,14 @@ int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_
                            stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, 0, (hipStream_t)stream);
 }
 
+int icap_stem_dwconv_nchw_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias, const float* w_dw,
+                              const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int img_h, int img_w,
+                              int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,
+                              void* stream) {
+    return stem_dwconv_f32(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, y, partial, B, img_h, img_w, Hs, Ws, C,
+                           stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, 8, (hipStream_t)stream);
+}
+
 int icap_stem_dwconv_bf16_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias, const float* w_dw,
                               const float* dw_scale, const float* dw_bias, void* y, int y_bf16, float* partial, int B, int img_h,
                               int img_w, int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,

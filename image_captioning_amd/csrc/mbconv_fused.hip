@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     const float* __restrict__ x, const float* __restrict__ we, const float* __restrict__ es, const float* __restrict__ eb,
     const float* __restrict__ wd, const float* __restrict__ dsc, const float* __restrict__ dbi, float* __restrict__ y,
     float* __restrict__ partial, int H, int W, int Cexp, int pad_t, int pad_l, int Ho, int Wo, int tiles_w, int cpg,
-    int img_h, int img_w, int stem_pad_t, int stem_pad_l, int out16) {
+    int img_h, int img_w, int stem_pad_t, int stem_pad_l, int flags) {
+    const int out16 = flags & 1;            // flags: bit 0 = bf16 output tensor, bit 1 (stem) = x is the planar [B][3][img_h][img_w] image
     static_assert(!STEM || CIN == 40, "the stem patch is 36 values padded to 40");
     static_assert(PROD == 0 || PROD == 1 || (PROD == 3 && !STEM), "split products: expanding blocks only");
     constexpr bool BF16 = PROD != 0;       // operands go through packed bf16 registers
@@ -97,8 +98,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
                 const int kh = tap / 3, kw = tap - kh * 3;
                 const int ih = hi * 2 - stem_pad_t + kh, iw = wi * 2 - stem_pad_l + kw;
                 const bool tok = ok && tap < 9 && (unsigned)ih < (unsigned)img_h && (unsigned)iw < (unsigned)img_w;
-                const float4 v = *reinterpret_cast<const float4*>(tok ? x + (((size_t)b * img_h + ih) * img_w + iw) * 4 : x);
-                af[i][4 * j] = v.x; af[i][4 * j + 1] = v.y; af[i][4 * j + 2] = v.z; af[i][4 * j + 3] = v.w;
+                if (flags & 2) {    // the reference's NCHW tensor as it is: one value per colour plane, the fourth channel is zero
+                    const size_t plane = (size_t)img_h * img_w;
+                    const float* src = tok ? x + ((size_t)b * 3 * img_h + ih) * img_w + iw : x;
+                    af[i][4 * j] = src[0]; af[i][4 * j + 1] = src[tok ? plane : 0]; af[i][4 * j + 2] = src[tok ? 2 * plane : 0]; af[i][4 * j + 3] = 0.f;
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(tok ? x + (((size_t)b * img_h + ih) * img_w + iw) * 4 : x);
+                    af[i][4 * j] = v.x; af[i][4 * j + 1] = v.y; af[i][4 * j + 2] = v.z; af[i][4 * j + 3] = v.w;
+                }
                 tapmask[i] |= (tok || !ok || tap >= 9) ? (1u << j) : 0u;
             }
         } else {
@@ -475,7 +482,7 @@ int stem_dwconv_f32(const float* x, const float* ws, const float* ss, const floa
         return ICAP_ERR_ALIGN;
     }
     if (B > 65535) { set_error("stem_dwconv: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
-    const int out16 = (bf16 >> 1) & 1;     // bf16: bit 0 = bf16 products, bit 1 = bf16 output tensor
+    const int out16 = ((bf16 >> 1) & 1) | ((bf16 >> 3) & 1) << 1;     // bf16: bit 0 = bf16 products, bit 1 = bf16 output tensor, bit 3 = x is planar NCHW
     bf16 &= 1;
     const int tiles_w = (Wo + STEM_TW - 1) / STEM_TW;
     const int ntiles = ((Ho + STEM_TH - 1) / STEM_TH) * tiles_w;

@@ -635,14 +635,22 @@ def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, k
     return y, partial
 
 
+STEM_NCHW = True       # fp32 modes: the fused stem kernel reads the planar NCHW image directly (False: interleave + pad pass first)
+
+
 def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, stem_pad=(0, 1, 0, 1), pad=(1, 1, 1, 1), want_partial=False,
-                  out_bf16=False):
-    """x [B,H,W,4] (image, channels padded to 4), w_stem [C,3,3,4], w_dw [9, C] ->
+                  out_bf16=False, nchw=False):
+    """x [B,H,W,4] (image, channels padded to 4) - or, with nchw=True, the planar fp32 image [B,3,H,W] as the reference hands it
+    over (fp32 modes only) -, w_stem [C,3,3,4], w_dw [9, C] ->
     (swish(bn(dw3x3(swish(bn(conv3x3 stride 2 (x)))))), partial): EfficientNet stem + block 0's depthwise convolution."""
-    B, H, W, c4 = x.shape
+    if nchw:
+        B, c4, H, W = x.shape
+        c4 += 1
+    else:
+        B, H, W, c4 = x.shape
     Cc = w_stem.shape[0]
     if c4 != 4 or tuple(w_stem.shape[1:]) != (3, 3, 4) or tuple(w_dw.shape) != (9, Cc):
-        raise IcapError("stem_dwconv2d: x must be [B,H,W,4], w_stem [C,3,3,4], w_dw [9,C]")
+        raise IcapError("stem_dwconv2d: x must be [B,H,W,4] (or [B,3,H,W] with nchw=True), w_stem [C,3,3,4], w_dw [9,C]")
     Hs = conv_out_size(H, 3, 2, stem_pad[0], stem_pad[1])
     Ws = conv_out_size(W, 3, 2, stem_pad[2], stem_pad[3])
     Ho = conv_out_size(Hs, 3, 1, pad[0], pad[1])
@@ -658,8 +666,12 @@ def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, 
     head = (_ck(x, "x"), _ck(w_stem, "w_stem"), _ck(stem_scale, "stem_scale"), _ck(stem_bias, "stem_bias"), _ck(w_dw, "w_dw"),
             _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"))
     tail = (_ck(partial, "partial"), B, H, W, Hs, Ws, Cc, stem_pad[0], stem_pad[2], pad[0], pad[2], Ho, Wo, _stream())
+    if nchw and bf16:
+        raise IcapError("stem_dwconv2d: the planar image is taken in the fp32 modes only")
     if bf16:
         N.check(lib.icap_stem_dwconv_bf16_f32(*head, _ck(y, "y", ydt), int(out_bf16), *tail), "stem_dwconv2d")
+    elif nchw:
+        N.check(lib.icap_stem_dwconv_nchw_f32(*head, _ck(y, "y"), *tail), "stem_dwconv2d")
     else:
         N.check(lib.icap_stem_dwconv_f32(*head, _ck(y, "y"), *tail), "stem_dwconv2d")
     span.done()

@@ -125,6 +125,13 @@ int icap_stem_dwconv_f32(const float* x, const float* w_stem, const float* stem_
                          const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial, int B,
                          int img_h, int img_w, int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l,
                          int Ho, int Wo, void* stream);
+/* The same with x the image as the reference hands it over, planar NCHW fp32 [B][3][img_h][img_w] (w_stem stays [C][3][3][4]
+ * with a zero fourth channel): saves the pass that would interleave and pad the image first
+ * (transformer_word_level.py:99 feeds `self.cnn_model(images)` such a tensor). */
+int icap_stem_dwconv_nchw_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias,
+                              const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial, int B,
+                              int img_h, int img_w, int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l,
+                              int Ho, int Wo, void* stream);
 int icap_stem_dwconv_chunks(int Ho, int Wo, int C);
 
 /* icap_expand_dwconv_f32 with its expand GEMM as fp32-ACCURATE products on the bf16 matrix cores (exact three-way bf16

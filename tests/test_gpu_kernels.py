@@ -180,6 +180,10 @@ def test_fused_stem_dwconv(H, W):
                                 stem_pad=sp, pad=(1, 1, 1, 1), want_partial=True)
     close(y.permute(0, 3, 1, 2), ref, what="stem+dwconv")
     close(part.sum(1) / (ref.shape[2] * ref.shape[3]), ref.mean((2, 3)), what="stem+dwconv partial pool")
+    # the planar NCHW image read directly (icap_stem_dwconv_nchw_f32): the same arithmetic on the same values, bit for bit
+    y2, part2 = ops.stem_dwconv2d(x.to(d), ws4.to(d), ss.to(d), sb.to(d), wd.view(C, 9).t().contiguous().to(d), dsc.to(d), dbi.to(d),
+                                  stem_pad=sp, pad=(1, 1, 1, 1), want_partial=True, nchw=True)
+    assert torch.equal(y2, y) and torch.equal(part2, part)
 
 
 def test_pools():

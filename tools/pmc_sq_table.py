@@ -1,11 +1,11 @@
 """Per-kernel table of the SQ counter pass (rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS), means per launch.
 usage: pmc_sq_table.py counter_collection.csv [substring ...]   (kernels whose name contains any substring; default: the
-MBConv, split-product GEMM, depthwise and squeeze-excite kernels)"""
+MBConv, split-product GEMM, projection, depthwise and squeeze-excite kernels)"""
 import csv, re, sys
 from collections import defaultdict
 
-subs = sys.argv[2:] or ["expand_dw", "gemm_bf16_kernel", "dwconv_strip", "se_gate", "gemm_x3dl"]
+subs = sys.argv[2:] or ["expand_dw", "gemm_bf16_kernel", "dwconv_strip", "se_gate", "gemm_x3dl", "gemm_x3t", "thin_project"]
 disp = {}
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"]

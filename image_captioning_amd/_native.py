@@ -122,6 +122,8 @@ SIGNATURES = {
     "icap_greedy_bah_ws_floats": (_ll, [_i] * 5),
     "icap_linear_thin_supported": (_i, [_i] * 2),
     "icap_linear_f32x3_tall_supported": (_i, [_i] * 4),
+    "icap_linear_f32x3_splitk_ws_floats": (_ll, [_i] * 3),
+    "icap_linear_f32x3_splitk_f32": (_i, [_p] * 6 + [_i, _p, _p, _ll] + [_i] * 6 + [_p]),
     "icap_linear_thin_f32": (_i, [_p] * 6 + [_i, _p, _ll, _i, _i, _p]),
     "icap_greedy_bah_persist_max_nb": (_i, [_i] * 2),
     "icap_greedy_bah_persist_ws_bytes": (_ll, [_i] * 3),

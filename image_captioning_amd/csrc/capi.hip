@@ -37,6 +37,9 @@ long long greedy_tfm_persist_ws_bytes(int, int, int, int);
 int greedy_tfm_persist_f32(const icap_tfm_weights*, const float*, const long long*, long long*, float*, void*, int, int, hipStream_t);
 int linear_thin_supported(int, int);
 int linear_f32x3_tall_supported(int, int, int, int);
+long long linear_f32x3_splitk_ws_floats(int, int, int);
+int linear_f32x3_splitk_f32(const float*, const unsigned short*, const float*, const float*, const float*, const float*, int, float*, float*,
+                            long long, int, int, int, int, int, int, hipStream_t);
 int linear_thin_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, float*, long long, int, int,
                     hipStream_t);
 int greedy_bah_persist_max_nb(int, int);
@@ -632,6 +635,12 @@ int icap_table_walk(const long long* next, const long long* start, long long* id
 
 int icap_linear_thin_supported(int K, int N) { return linear_thin_supported(K, N); }
 int icap_linear_f32x3_tall_supported(int K, int N, int hw, int gated) { return linear_f32x3_tall_supported(K, N, hw, gated); }
+long long icap_linear_f32x3_splitk_ws_floats(int M, int N, int ksplit) { return linear_f32x3_splitk_ws_floats(M, N, ksplit); }
+int icap_linear_f32x3_splitk_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
+                                 const float* gate, int hw, float* y, float* ws, long long ws_floats, int M, int K, int N, int act, int cfg,
+                                 int ksplit, void* stream) {
+    return linear_f32x3_splitk_f32(x, w3, scale, bias, residual, gate, hw, y, ws, ws_floats, M, K, N, act, cfg, ksplit, (hipStream_t)stream);
+}
 int icap_linear_thin_f32(const float* x, const float* w, const float* scale, const float* bias, const float* residual, const float* gate,
                          int hw, float* y, long long M, int K, int N, void* stream) {
     return linear_thin_f32(x, w, scale, bias, residual, gate, hw, y, M, K, N, (hipStream_t)stream);

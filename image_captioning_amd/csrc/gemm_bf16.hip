@@ -34,6 +34,8 @@ struct GemmBf16Params {
     int y16, res16;         // y is stored / residual is read as bf16 [M][N] (activations kept in bf16 between layers)
     int m_fast;             // tile order inside an XCD's range: 1 = consecutive tiles share a W panel, 0 = an A panel
     float* stat_part;       // optional [P][2][N]: column sum and squared deviations of every BM-row tile of the result
+    int ksl;                // linear form only: K slice per blockIdx.z (0 = the whole contraction); slice z writes its partial
+                            // products to y + z M N (no scale / bias / residual / activation: the reduction applies them)
 };
 
 // Workgroups go to the 8 XCDs round-robin by blockIdx and every XCD has its own L2.  Mapped naively (tile = blockIdx), the
@@ -118,6 +120,9 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
     int tile_m, tile_n;
     gb16_tile(p, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int koff = p.ksl ? (int)blockIdx.z * p.ksl : 0;                  // this workgroup's K slice [koff, koff + klen)
+    const int klen = p.ksl ? min(p.ksl, p.K - koff) : p.K;
+    float* const y_out = p.y ? p.y + (p.ksl ? (size_t)blockIdx.z * p.M * p.N : 0) : nullptr;
 
     // staging coordinates
     const int a_k4 = (tid & 7) * 4, a_row = tid >> 3;
@@ -140,9 +145,9 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
             a_iw[i] = ow * p.stride - p.pad_l;
             a_src[i] = p.x + (size_t)b * p.H * p.W * p.Cin;
         } else {
-            a_src[i] = p.x + (size_t)(a_ok[i] ? m : 0) * p.K;
+            a_src[i] = p.x + (size_t)(a_ok[i] ? m : 0) * p.K + koff;
         }
-        if (GATE) g_src[i] = p.gate + (size_t)((a_ok[i] ? m : 0) / p.hw) * p.K;
+        if (GATE) g_src[i] = p.gate + (size_t)((a_ok[i] ? m : 0) / p.hw) * p.K + koff;
     }
     int c_kh = 0, c_kw = 0, c_c0 = 0;                   // CONV: filter tap and first channel of the slice gload fetches next
     // bf16 A: staged like W (thread t -> row t/4 + 64 i, eight bf16 at 8 (t%4))
@@ -164,9 +169,9 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                 a16_iw[i] = ow * p.stride - p.pad_l;
                 a16_src[i] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)b * p.H * p.W * p.Cin;
             } else {
-                a16_src[i] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)(a16_ok[i] ? m : 0) * p.K;
+                a16_src[i] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)(a16_ok[i] ? m : 0) * p.K + koff;
             }
-            if constexpr (GATE) g16_src[i] = p.gate + (size_t)((a16_ok[i] ? m : 0) / p.hw) * p.K;
+            if constexpr (GATE) g16_src[i] = p.gate + (size_t)((a16_ok[i] ? m : 0) / p.hw) * p.K + koff;
         }
     }
     const unsigned short* b_src[BP];
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
     for (int i = 0; i < BP; ++i) {
         const int n = n0 + b_row + 64 * i;
         b_ok[i] = (b_row + 64 * i < BN) && n < p.N;
-        b_src[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K;
+        b_src[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K + koff;
     }
 
     constexpr int NSET = 1;                          // staging register sets (K slices in flight)
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
         if constexpr (A16) {
 #pragma unroll
             for (int i = 0; i < AP16; ++i) {
-                bool ok = a16_ok[i] && kb < p.K;
+                bool ok = a16_ok[i] && kb < klen;
                 const unsigned short* src = a16_src[i] + kb;
                 if constexpr (CONV == 1) {
                     const int ih = a16_ih[i] + c_kh, iw = a16_iw[i] + c_kw;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                 ra[S][i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ((size_t)ih * p.W + iw) * 4 : p.x);
                 okmask |= ok ? (1u << i) : 0u;
             } else {
-                const bool ok = a_ok[i] && ka < p.K;
+                const bool ok = a_ok[i] && ka < klen;
                 ra[S][i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ka : p.x);
                 if (GATE) rg[S][i] = *reinterpret_cast<const float4*>(ok ? g_src[i] + ka : p.gate);
                 okmask |= ok ? (1u << i) : 0u;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            const bool ok = b_ok[i] && kb < p.K;
+            const bool ok = b_ok[i] && kb < klen;
 #pragma unroll
             for (int sp = 0; sp < SPLIT; ++sp)
                 rb[S][sp][i] = *reinterpret_cast<const uint4*>(ok ? b_src[i] + (size_t)sp * p.N * p.K + kb : p.w);
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
         }
     };
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (klen + BK - 1) / BK;
     using T0 = std::integral_constant<int, 0>;
     gload(0, T0{});
     lds_store(0, T0{});
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                         p.amax_val[(size_t)m * p.tiles_n + tile_n] = bv;
                         p.amax_idx[(size_t)m * p.tiles_n + tile_n] = bidx;
                     }
-                    if (!p.y) continue;
+                    if (!y_out) continue;
                 }
                 if (m >= p.M || n >= p.N) continue;
                 float4 v = *reinterpret_cast<const float4*>(&ep[row * EP_LD + en4 * 4]);
@@ -457,8 +462,8 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                     }
                 }
                 v.x = act_c<ACT>(v.x); v.y = act_c<ACT>(v.y); v.z = act_c<ACT>(v.z); v.w = act_c<ACT>(v.w);
-                if (p.y16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + o) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
-                else *reinterpret_cast<float4*>(p.y + o) = v;
+                if (p.y16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y_out) + o) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+                else *reinterpret_cast<float4*>(y_out + o) = v;
             }
             if (STATS && pass == NPASS - 1) {
                 // column statistics of the result for the BatchNorm that follows: the row groups' shifted moments meet in
@@ -712,6 +717,71 @@ int linear_f32x3_f32(const float* x, int x_split, const unsigned short* w3, cons
         case 2: return gate ? gb16_split_launch<64, 64, true, false>(p, st) : gb16_split_launch<64, 64, false, false>(p, st);
         default: set_error("linear_f32x3: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
     }
+}
+
+// ---- split-K form for layers with few output tiles and a long contraction (the decoder's 2048 -> 512 Linear at 1024 rows: 128
+// tiles of 64 x 64 on 256 CUs): KS slices of the contraction run as KS times as many workgroups, each writing its partial
+// products to ws [KS][M][N]; splitk_reduce_kernel adds the slices in order and applies the epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ks, const float* __restrict__ scale,
+                                                            const float* __restrict__ bias, const float* __restrict__ residual,
+                                                            float* __restrict__ y, long long mn4, int n4, int act) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mn4) return;
+    float4 v = reinterpret_cast<const float4*>(ws)[i];
+    for (int z = 1; z < ks; ++z) {
+        const float4 t = reinterpret_cast<const float4*>(ws)[(long long)z * mn4 + i];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const int c = (int)(i % n4);
+    if (scale) { const float4 s4 = reinterpret_cast<const float4*>(scale)[c]; v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
+    if (bias) { const float4 b4 = reinterpret_cast<const float4*>(bias)[c]; v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+    if (residual) { const float4 r4 = reinterpret_cast<const float4*>(residual)[i]; v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+    if (act != ACT_NONE) { v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act); }
+    reinterpret_cast<float4*>(y)[i] = v;
+}
+
+long long linear_f32x3_splitk_ws_floats(int M, int N, int ksplit) { return (long long)(ksplit > 1 ? ksplit : 0) * M * N; }
+
+// cfg: 0 = 128x128, 1 = 64x128, 2 = 64x64 tiles; ksplit 2 .. 16; K must split into ksplit slices of whole 32-wide K steps
+int linear_f32x3_splitk_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
+                            const float* gate, int hw, float* y, float* ws, long long ws_floats, int M, int K, int N, int act, int cfg,
+                            int ksplit, hipStream_t st) {
+    if (!y || !ws || (gate && hw <= 0) || ksplit < 2 || ksplit > 16) { set_error("linear_f32x3_splitk: bad arguments (ksplit 2 .. 16)"); return ICAP_ERR_ARG; }
+    const int rc = split_args_ok("linear_f32x3_splitk", x, w3, scale, bias, residual, gate, y, M, K, N);
+    if (rc != ICAP_OK) return rc;
+    if (K % (ksplit * GB16_BK)) { set_error("linear_f32x3_splitk: K=%d does not split into %d slices of whole %d-wide steps", K, ksplit, GB16_BK); return ICAP_ERR_ARG; }
+    if (!aligned16(ws) || ws_floats < linear_f32x3_splitk_ws_floats(M, N, ksplit)) {
+        set_error("linear_f32x3_splitk: the workspace must be 16-byte aligned and hold %lld floats", linear_f32x3_splitk_ws_floats(M, N, ksplit));
+        return ICAP_ERR_ARG;
+    }
+    GemmBf16Params p{x, w3, nullptr, nullptr, nullptr, gate, ws, M, N, K, gate ? hw : 1, ACT_NONE, 0, nullptr, nullptr};
+    p.ksl = K / ksplit;
+    auto launch = [&](auto bm, auto bn) -> int {
+        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
+        auto kern = gate ? gemm_bf16_kernel<BM, BN, true, false, false, 0, 3, false> : gemm_bf16_kernel<BM, BN, false, false, false, 0, 3, false>;
+        static hipError_t rc_t = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, true, false, false, 0, 3, false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, gb16_split_smem<BM, BN>());
+        static hipError_t rc_f = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, false, false, false, 0, 3, false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, gb16_split_smem<BM, BN>());
+        if (rc_t != hipSuccess || rc_f != hipSuccess) { set_error("linear_f32x3_splitk: cannot raise the dynamic LDS limit"); return ICAP_ERR_HIP_BASE; }
+        p.tiles_n = (p.N + BN - 1) / BN;
+        gb16_set_order(p, 4, 6);
+        const dim3 grid((unsigned)((long long)((p.M + BM - 1) / BM) * p.tiles_n), 1, (unsigned)ksplit), block(256);
+        constexpr int lds_bytes = gb16_split_smem<BM, BN>();
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, p);
+        return launch_status("linear_f32x3_splitk");
+    };
+    int lrc;
+    switch (cfg) {
+        case 0: lrc = launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{}); break;
+        case 1: lrc = launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 128>{}); break;
+        case 2: lrc = launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{}); break;
+        default: set_error("linear_f32x3_splitk: unknown tile configuration %d", cfg); return ICAP_ERR_ARG;
+    }
+    if (lrc != ICAP_OK) return lrc;
+    const long long mn4 = (long long)M * N / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, st, ws, ksplit, scale, bias, residual, y, mn4, N / 4, act);
+    return launch_status("linear_f32x3_splitk (reduce)");
 }
 
 // Plain split-product Linear (no scale, bias, residual, gate or activation) whose epilogue also leaves the column statistics

@@ -119,9 +119,10 @@ def linear_f32x3_tall_supported(K: int, Nn: int, hw: int = 1, gated: bool = Fals
     return bool(N.load().icap_linear_f32x3_tall_supported(K, Nn, hw, int(gated)))
 
 
-def _x3_pick(M, K, Nn, run_fp32, run_split, tall=False):
-    """tall: the layer can also run on the tall-activation kernel (cfg 3), which only the tuner picks."""
-    key = (M, K, Nn, tall)
+def _x3_pick(M, K, Nn, run_fp32, run_split, tall=False, splitk=()):
+    """tall: the layer can also run on the tall-activation kernel (cfg 3); splitk: split-K configurations ((slices << 4) | tile)
+    worth trying - both are picked by the tuner only."""
+    key = (M, K, Nn, tall, splitk)
     c = _x3_choice.get(key) if _X3_USE_TUNED else None
     if c is not None:
         return c
@@ -131,7 +132,7 @@ def _x3_pick(M, K, Nn, run_fp32, run_split, tall=False):
         tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
         return -1 if (K >= X3_MIN_K and tiles >= X3_MIN_TILES) else _X3_FP32
     best, best_ms = _X3_FP32, None
-    for cand in (_X3_FP32, 0, 1, 2) + ((3,) if tall else ()):
+    for cand in (_X3_FP32, 0, 1, 2) + ((3,) if tall else ()) + tuple(splitk):
         fn = run_fp32 if cand == _X3_FP32 else (lambda c=cand: run_split(c))
         for _ in range(2):
             fn()
@@ -180,6 +181,7 @@ def linear_thin(x, w, bias=None, scale=None, residual=None, gate=None, hw=1, out
 # tuner the tall-activation kernel (linear_f32x3 cfg 3).
 TALL_PROJECT = True
 TALL_MIN_ROWS = 16384
+SPLITK = True          # and layers of at most 256 64x64 tiles with K >= 1024 the split-K form
 
 
 def linear_x3_auto(x, w, w3_cache: dict, key, bias=None, scale=None, act=ACT_NONE, residual=None, gate=None, hw=1):
@@ -203,7 +205,11 @@ def linear_x3_auto(x, w, w3_cache: dict, key, bias=None, scale=None, act=ACT_NON
         return linear_f32x3(x, w3(), bias, scale, act=act, residual=residual, gate=gate, hw=hw, cfg=cfg)
 
     tall = TALL_PROJECT and act == ACT_NONE and M >= TALL_MIN_ROWS and linear_f32x3_tall_supported(K, Nn, hw, gate is not None)
-    c = _x3_pick(M, K, Nn, run_fp32, run_split, tall)
+    # few output tiles and a long contraction: also offer the split-K form (2 / 4 / 8 slices of whole 32-wide steps)
+    splitk = ()
+    if SPLITK and K >= 1024 and ((M + 63) // 64) * ((Nn + 63) // 64) <= 256:
+        splitk = tuple((ks << 4) | t for ks in (2, 4, 8) if K % (ks * 32) == 0 for t in (1, 2))
+    c = _x3_pick(M, K, Nn, run_fp32, run_split, tall, splitk)
     return run_fp32() if c == _X3_FP32 else run_split(c)
 
 
@@ -775,6 +781,9 @@ def split3(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_splitk_ws: dict = {}     # device -> the workspace of the split-K launches (launches on one stream run in order, so one is enough)
+
+
 def _x_planes(x):
     """(M, K, pre-split?) of an activation operand: an fp32 [M, K] matrix or its split3 planes, bf16 [3, M, K]."""
     if x.dtype == torch.bfloat16:
@@ -799,9 +808,22 @@ def linear_f32x3(x, w3, bias=None, scale=None, act=ACT_NONE, residual=None, gate
     if gate is not None and (pre or gate.shape[-1] != K or gate.shape[0] * hw != M):
         raise IcapError("linear_f32x3: gate must be [M // hw, K] (and x fp32)")
     span = _Span("linear_f32x3", (M, K, Nn, residual is not None, gate is not None))
-    N.check(N.load().icap_linear_f32x3_f32(_ck(x, "x", x.dtype), int(pre), _ck(w3, "w3", torch.bfloat16), _ck(scale, "scale"),
-                                           _ck(bias, "bias"), _ck(residual, "residual"), _ck(gate, "gate"), hw, _ck(out, "out"), M, K,
-                                           Nn, act, cfg, _stream()), "linear_f32x3")
+    if cfg >= 16:       # split-K: cfg = (slices << 4) | tile configuration; partial products go through a cached workspace
+        if pre:
+            raise IcapError("linear_f32x3: the split-K form takes fp32 activations")
+        ks = cfg >> 4
+        lib = N.load()
+        need = lib.icap_linear_f32x3_splitk_ws_floats(M, Nn, ks)
+        ws = _splitk_ws.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = _splitk_ws[x.device] = torch.empty(need, device=x.device, dtype=torch.float32)
+        N.check(lib.icap_linear_f32x3_splitk_f32(_ck(x, "x"), _ck(w3, "w3", torch.bfloat16), _ck(scale, "scale"), _ck(bias, "bias"),
+                                                 _ck(residual, "residual"), _ck(gate, "gate"), hw, _ck(out, "out"), ws.data_ptr(), ws.numel(),
+                                                 M, K, Nn, act, cfg & 15, ks, _stream()), "linear_f32x3_splitk")
+    else:
+        N.check(N.load().icap_linear_f32x3_f32(_ck(x, "x", x.dtype), int(pre), _ck(w3, "w3", torch.bfloat16), _ck(scale, "scale"),
+                                               _ck(bias, "bias"), _ck(residual, "residual"), _ck(gate, "gate"), hw, _ck(out, "out"), M, K,
+                                               Nn, act, cfg, _stream()), "linear_f32x3")
     span.done()
     return out
 

@@ -246,6 +246,15 @@ int icap_linear_thin_f32(const float* x, const float* w, const float* scale, con
  * images of at least 43 pixels).  Replaces the same nn.Linear / 1x1 convolution sites as icap_conv2d_f32. */
 int icap_split3_f32(const float* src, unsigned short* dst, long long n, void* stream);
 int icap_linear_f32x3_tall_supported(int K, int N, int hw, int gated);
+/* icap_linear_f32x3_f32 (fp32 x) with the contraction cut into ksplit (2 .. 16) slices of whole 32-wide steps, for layers with
+ * few output tiles and a long contraction (the word decoder's 2048 -> 512 Linear at 1024 rows, transformer_word_level.py:77:
+ * 128 tiles on 256 CUs): ksplit times as many workgroups write partial products to ws (icap_linear_f32x3_splitk_ws_floats(M, N,
+ * ksplit) floats, caller-owned, overwritten), a second launch adds the slices in a fixed order and applies scale, bias,
+ * residual and activation.  cfg 0 .. 2 as in icap_linear_f32x3_f32 (no -1). */
+long long icap_linear_f32x3_splitk_ws_floats(int M, int N, int ksplit);
+int icap_linear_f32x3_splitk_f32(const float* x, const unsigned short* w3, const float* scale, const float* bias, const float* residual,
+                                 const float* gate, int hw, float* y, float* ws, long long ws_floats, int M, int K, int N, int act,
+                                 int cfg, int ksplit, void* stream);
 int icap_linear_f32x3_f32(const void* x, int x_split, const unsigned short* w3, const float* scale, const float* bias,
                           const float* residual, const float* gate, int hw, float* y, int M, int K, int N, int act, int cfg,
                           void* stream);

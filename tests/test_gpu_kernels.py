@@ -493,3 +493,27 @@ def test_linear_f32x3_tall(M, K, N, hw, use_res, use_gate):
     assert not ops.linear_f32x3_tall_supported(96, 16, 36, True)
     with pytest.raises(ops.IcapError):
         ops.linear_f32x3(torch.zeros(64, 64, device=d), ops.split3(torch.zeros(16, 64, device=d)), cfg=3)
+
+
+@pytest.mark.parametrize("M,K,N,ks,cfg,use_res,use_gate,act", [
+    (1024, 2048, 512, 4, 2, True, False, 0), (300, 1024, 260, 2, 1, False, False, 1), (130, 512, 68, 8, 2, True, False, 2),
+    (49 * 6, 1152, 192, 4, 0, True, True, 0), (64, 1024, 64, 16, 2, False, False, 0)])
+def test_linear_f32x3_splitk(M, K, N, ks, cfg, use_res, use_gate, act):
+    """Split-K form of the split-product layer (slices of the contraction in grid.z, partial products through a workspace, ordered
+    reduction with the epilogue) against the one-pass kernel: ragged tiles, every tile configuration, gate, residual, activation."""
+    from image_captioning_amd import ops
+    d = dev()
+    hw = 49 if use_gate else 1
+    x, w, b = rnd(M, K, seed=1).to(d), rnd(N, K, seed=2, scale=K ** -0.5).to(d), rnd(N, seed=3).to(d)
+    scale = (torch.rand(N, generator=torch.Generator().manual_seed(4)) + 0.5).to(d)
+    res = rnd(M, N, seed=5).to(d) if use_res else None
+    gate = torch.rand(M // hw, K, generator=torch.Generator().manual_seed(6)).to(d) if use_gate else None
+    w3 = ops.split3(w)
+    one = ops.linear_f32x3(x, w3, b, scale, act=act, residual=res, gate=gate, hw=hw, cfg=2)
+    got = ops.linear_f32x3(x, w3, b, scale, act=act, residual=res, gate=gate, hw=hw, cfg=(ks << 4) | cfg)
+    again = ops.linear_f32x3(x, w3, b, scale, act=act, residual=res, gate=gate, hw=hw, cfg=(ks << 4) | cfg)
+    assert torch.equal(got, again)                              # fixed reduction order
+    tol = 4e-6 * float(one.abs().max())                         # the same products, summed in another order
+    assert float((got - one).abs().max()) <= tol
+    with pytest.raises(ops.IcapError):                          # K must split into whole 32-wide steps
+        ops.linear_f32x3(x[:, :K - 32].contiguous(), ops.split3(w[:, :K - 32].contiguous()), cfg=(16 << 4) | 2)

@@ -110,10 +110,12 @@ def expand_dw_work(sig):
 
 
 def stem_dw_work(sig):
-    """(B, H, W, C, Hs, Ws, Ho, Wo): 3x3x3 stem + 3x3 depthwise; the 4-channel-padded image read once, the output written once."""
+    """(B, H, W, C, Hs, Ws, Ho, Wo, bf16 result, planar input): 3x3x3 stem + 3x3 depthwise; the image (three planes, or four
+    interleaved channels) read once, the output written once."""
     B, H, W, C, Hs, Ws, Ho, Wo = sig[:8]
     ob = 2.0 if (len(sig) > 8 and sig[8]) else 4.0
-    return 2.0 * B * Hs * Ws * 27 * C + 2.0 * B * Ho * Wo * C * 9, 4.0 * B * H * W * 4 + ob * B * Ho * Wo * C
+    cin = 3 if (len(sig) > 9 and sig[9]) else 4
+    return 2.0 * B * Hs * Ws * 27 * C + 2.0 * B * Ho * Wo * C * 9, 4.0 * B * H * W * cin + ob * B * Ho * Wo * C
 
 
 def linear_x3_work(sig):

@@ -668,7 +668,7 @@ def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, 
     ydt = torch.bfloat16 if out_bf16 else torch.float32
     y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=ydt)
     partial = torch.empty((B, lib.icap_stem_dwconv_chunks(Ho, Wo, Cc), Cc), device=x.device, dtype=torch.float32) if want_partial else None
-    span = _Span("stem_dwconv2d", (B, H, W, Cc, Hs, Ws, Ho, Wo, out_bf16))
+    span = _Span("stem_dwconv2d", (B, H, W, Cc, Hs, Ws, Ho, Wo, out_bf16, bool(nchw)))
     head = (_ck(x, "x"), _ck(w_stem, "w_stem"), _ck(stem_scale, "stem_scale"), _ck(stem_bias, "stem_bias"), _ck(w_dw, "w_dw"),
             _ck(dw_scale, "dw_scale"), _ck(dw_bias, "dw_bias"))
     tail = (_ck(partial, "partial"), B, H, W, Hs, Ws, Cc, stem_pad[0], stem_pad[2], pad[0], pad[2], Ho, Wo, _stream())

@@ -1,4 +1,4 @@
-# Round-3 profiles of the final tree: rocprofv3 kernel stats of the default bench command (captioning) and of the training
+# Profiles of the current tree: rocprofv3 kernel stats of the default bench command (captioning) and of the training
 # bench, the timed-window summary, and the SQ / TCC counter passes (one pass per counter group).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

@@ -75,6 +75,8 @@ SIGNATURES = {
     "icap_expand_dwconv_img_x3_f32": (_i, [_p] * 9 + [_i] * 8 + [_p]),
     "icap_stem_dwconv_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),
     "icap_stem_dwconv_nchw_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),
+    "icap_stem_dwconv_valu_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),
+    "icap_stem_dwconv_valu_supported": (_i, [_i]),
     "icap_stem_dwconv_chunks": (_i, [_i] * 3),
     "icap_expand_dwconv_bf16_f32": (_i, [_p] * 8 + [_i, _p] + [_i] * 11 + [_p]),
     "icap_stem_dwconv_bf16_f32": (_i, [_p] * 8 + [_i, _p] + [_i] * 12 + [_p]),

@@ -305,6 +305,7 @@ class EfficientNetB0(nn.Module):
 
     def _build(self):
         p = {"stem_w": conv_weight_khwc(self._conv_stem.weight, 4), "stem_sb": fold_bn(self._bn0), "blocks": []}
+        p["stem_wk"] = ops.stem_weight_k(p["stem_w"])           # k-major copy for the vector-ALU stem kernel
         for b in self._blocks:
             mid = b.cin * b.expand
             d = {"k": b.k, "stride": b.stride, "skip": b.stride == 1 and b.cin == b.cout, "expand": None}
@@ -336,7 +337,7 @@ class EfficientNetB0(nn.Module):
             # the stem's 112x112x32 output feeds only block 0's depthwise convolution: both run in one kernel
             # (in bf16 mode the fused kernels hand their result to the project convolution as a bf16 tensor)
             h, part = ops.stem_dwconv2d(x, p["stem_w"], *p["stem_sb"], d0["dw_w"], *d0["dw_sb"], stem_pad=(lo, hi, lo, hi),
-                                        pad=(1, 1, 1, 1), want_partial=True, nchw=planar,
+                                        pad=(1, 1, 1, 1), want_partial=True, nchw=planar, w_stem_k=p.get("stem_wk"),
                                         out_bf16=ops.bf16_activations_ok(d0["dw_w"].shape[1], d0["proj"][0].shape[0]))
             gate = ops.se_gate(part, h.shape[1] * h.shape[2], *d0["se"])
             x = ops.pointwise_conv(h, d0["proj"][0], d0, "proj16", *d0["proj"][1], gate=gate)

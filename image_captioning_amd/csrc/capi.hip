@@ -92,6 +92,9 @@ int expand_dwconv_img_x3_f32(const float*, const void*, const float*, const floa
 int stem_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                     float*, int, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int stem_dwconv_chunks(int, int, int);
+int stem_dwconv_valu_supported(int);
+int stem_dwconv_valu_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*,
+                         int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int se_gate_f32(const float*, int, float, const float*, const float*, const float*, const float*, float*, int, int, int,
                 hipStream_t);
 int maxpool2d_f32(const float*, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -339,6 +342,15 @@ int icap_stem_dwconv_nchw_f32(const float* x, const float* w_stem, const float* 
                               void* stream) {
     return stem_dwconv_f32(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, y, partial, B, img_h, img_w, Hs, Ws, C,
                            stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, 8, (hipStream_t)stream);
+}
+
+int icap_stem_dwconv_valu_supported(int C) { return stem_dwconv_valu_supported(C); }
+int icap_stem_dwconv_valu_f32(const float* x, const float* w_stem_k, const float* stem_scale, const float* stem_bias, const float* w_dw,
+                              const float* dw_scale, const float* dw_bias, float* y, float* partial, int B, int img_h, int img_w,
+                              int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,
+                              void* stream) {
+    return stem_dwconv_valu_f32(x, w_stem_k, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, y, partial, B, img_h, img_w, Hs, Ws, C,
+                                stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, (hipStream_t)stream);
 }
 
 int icap_stem_dwconv_bf16_f32(const float* x, const float* w_stem, const float* stem_scale, const float* stem_bias, const float* w_dw,

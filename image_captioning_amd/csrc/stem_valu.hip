@@ -1,0 +1,197 @@
+// EfficientNet-B0 stem (3x3 stride-2 convolution of the planar fp32 image, folded BN, swish) fused with block 0's depthwise
+// 3x3 stride-1 convolution (+ folded BN + swish + the squeeze-excite partial sums), on the vector ALUs alone:
+//   * the 33 x 33 x 3 image patch under the tile is fetched into LDS in one go (every load of the tile in flight at once);
+//   * a thread owns ONE stem pixel of the tile's 16 x 16 stem region (the 14 x 14 output tile + the depthwise halo) and all
+//     32 channels: it reads its 27 image values from the patch tap by tap, the weights w[k][c] are the same for every lane, so they come
+//     through the scalar cache as instruction operands, and the 864 multiply-adds are packed two channels per instruction;
+//     nothing depends on a matrix-instruction chain and ~100 registers leave five waves per SIMD to hide the loads;
+//   * BN + swish, zero for stem pixels outside the stem's output (the depthwise convolution pads with zeros), then the tile
+//     goes to LDS once ([256 pixels][32 + 4 channels]);
+//   * depthwise phase: a thread owns a strip of 7 output pixels x 4 channels, slides over the 3 x 9 window of LDS rows,
+//     applies BN + swish, stores 16 bytes per pixel (eight lanes = one pixel's 128-byte line) and adds up its outputs for
+//     the per-tile channel sums.
+#include "common.hpp"
+
+namespace icap {
+
+typedef float sv_f32x2 __attribute__((ext_vector_type(2)));
+typedef float sv_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SV_C = 32, SV_TH = 14, SV_TW = 14, SV_EH = SV_TH + 2, SV_EW = SV_TW + 2, SV_LDE = SV_C + 4, SV_SW = 7;
+constexpr int SV_PH = 2 * SV_EH + 1, SV_PW = 2 * SV_EW + 1, SV_PP = SV_PW + 1;     // image patch rows / columns / row pitch
+static_assert(SV_EH * SV_EW == 256, "one thread per stem pixel of the tile's region");
+
+__global__ __launch_bounds__(256) void stem_dw_valu_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+                                                            const float* __restrict__ ss, const float* __restrict__ sb,
+                                                            const float* __restrict__ wd, const float* __restrict__ dsc,
+                                                            const float* __restrict__ dbi, float* __restrict__ y,
+                                                            float* __restrict__ partial, int img_h, int img_w, int Hs, int Ws,
+                                                            int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo,
+                                                            int tiles_w) {
+    __shared__ __attribute__((aligned(16))) float E[SV_EH * SV_EW * SV_LDE];
+    __shared__ float X[3 * SV_PH * SV_PP];       // the image patch under the tile's stem region: [plane][33 rows][33 (+1) columns]
+    __shared__ sv_f32x4 red[4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tile = blockIdx.x;
+    const int th_i = tile / tiles_w;
+    const int ho0 = th_i * SV_TH, wo0 = (tile - th_i * tiles_w) * SV_TW;
+
+    // ---- the image patch: every element requested at once (one memory latency per tile), zeros outside the image
+    {
+        const size_t plane = (size_t)img_h * img_w;
+        const float* xb = x + (size_t)b * 3 * plane;
+        const int ih0 = (ho0 - pad_t) * 2 - stem_pad_t, iw0 = (wo0 - pad_l) * 2 - stem_pad_l;
+        constexpr int NEL = 3 * SV_PH * SV_PW, PER = (NEL + 255) / 256;
+        float v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + 256 * i;
+            const int pl = e / (SV_PH * SV_PW), rem = e - pl * (SV_PH * SV_PW);
+            const int pr = rem / SV_PW, pc = rem - pr * SV_PW;
+            const int ih = ih0 + pr, iw = iw0 + pc;
+            const bool ok = e < NEL && (unsigned)ih < (unsigned)img_h && (unsigned)iw < (unsigned)img_w;
+            const float t = xb[ok ? pl * plane + (size_t)ih * img_w + iw : 0];       // a select on the address, never a branch
+            v[i] = ok ? t : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + 256 * i;
+            const int pl = e / (SV_PH * SV_PW), rem = e - pl * (SV_PH * SV_PW);
+            const int pr = rem / SV_PW, pc = rem - pr * SV_PW;
+            if (e < NEL) X[(pl * SV_PH + pr) * SV_PP + pc] = v[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- stem: this thread's pixel of the 16 x 16 region
+    {
+        const int sy = tid >> 4, sx = tid & 15;
+        const int hs = ho0 - pad_t + sy, wsx = wo0 - pad_l + sx;
+        const bool inside = (unsigned)hs < (unsigned)Hs && (unsigned)wsx < (unsigned)Ws;
+        sv_f32x2 acc[SV_C / 2];
+#pragma unroll
+        for (int c2 = 0; c2 < SV_C / 2; ++c2) acc[c2] = sv_f32x2{0.f, 0.f};
+        const sv_f32x2* wk2 = reinterpret_cast<const sv_f32x2*>(wk);              // [27][16] channel pairs, uniform addresses
+        const float* xp = X + (2 * sy) * SV_PP + 2 * sx;
+        // one filter tap per trip (not unrolled: the 96 weights of a tap fit the scalar registers, all 864 would not)
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            float xv[3];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) xv[ci] = xp[(ci * SV_PH + kh) * SV_PP + kw];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const sv_f32x2 xk = {xv[ci], xv[ci]};
+                const sv_f32x2* wrow = wk2 + (tap * 3 + ci) * (SV_C / 2);
+#pragma unroll
+                for (int c2 = 0; c2 < SV_C / 2; ++c2) acc[c2] = __builtin_elementwise_fma(xk, wrow[c2], acc[c2]);
+            }
+        }
+        const sv_f32x2* ss2 = reinterpret_cast<const sv_f32x2*>(ss);
+        const sv_f32x2* sb2 = reinterpret_cast<const sv_f32x2*>(sb);
+        float* erow = E + tid * SV_LDE;
+#pragma unroll
+        for (int c4 = 0; c4 < SV_C / 4; ++c4) {
+            sv_f32x4 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c2 = 2 * c4 + h;
+                sv_f32x2 v = acc[c2];
+                if (ss) v = v * ss2[c2];
+                if (sb) v = v + sb2[c2];
+                o[2 * h] = inside ? v[0] * sigmoid_fast(v[0]) : 0.f;
+                o[2 * h + 1] = inside ? v[1] * sigmoid_fast(v[1]) : 0.f;
+            }
+            *reinterpret_cast<sv_f32x4*>(erow + 4 * c4) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- depthwise 3x3: strip st (row r, 7 columns) x channel quad q
+    const int q = tid & 7, st = tid >> 3;
+    sv_f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (st < SV_TH * (SV_TW / SV_SW)) {
+        const int r = st >> 1, col0 = (st & 1) * SV_SW;
+        sv_f32x4 w9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w9[t] = *reinterpret_cast<const sv_f32x4*>(wd + t * SV_C + 4 * q);
+        sv_f32x4 o[SV_SW];
+#pragma unroll
+        for (int j = 0; j < SV_SW; ++j) o[j] = sv_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < SV_SW + 2; ++dx) {
+                const sv_f32x4 e = *reinterpret_cast<const sv_f32x4*>(E + ((r + dy) * SV_EW + col0 + dx) * SV_LDE + 4 * q);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int j = dx - kx;
+                    if (j >= 0 && j < SV_SW) o[j] = __builtin_elementwise_fma(e, w9[dy * 3 + kx], o[j]);
+                }
+            }
+        sv_f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (dsc) sc = *reinterpret_cast<const sv_f32x4*>(dsc + 4 * q);
+        if (dbi) bi = *reinterpret_cast<const sv_f32x4*>(dbi + 4 * q);
+        const int ho = ho0 + r;
+#pragma unroll
+        for (int j = 0; j < SV_SW; ++j) {
+            const int wo = wo0 + col0 + j;
+            sv_f32x4 v = o[j] * sc + bi;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = v[t] * sigmoid_fast(v[t]);
+            if (ho < Ho && wo < Wo) {
+                *reinterpret_cast<sv_f32x4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * SV_C + 4 * q) = v;
+                sum += v;
+            }
+        }
+    }
+    if (partial) {
+        // per-channel sum over the tile in a fixed order: lanes with equal q inside a wave, then the four waves
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            sum[0] += __shfl_xor(sum[0], off, 64); sum[1] += __shfl_xor(sum[1], off, 64);
+            sum[2] += __shfl_xor(sum[2], off, 64); sum[3] += __shfl_xor(sum[3], off, 64);
+        }
+        if (lane < 8) red[wave][lane] = sum;
+        __syncthreads();
+        if (tid < 8) {
+            const sv_f32x4 t = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            *reinterpret_cast<sv_f32x4*>(partial + ((size_t)b * gridDim.x + tile) * SV_C + 4 * tid) = t;
+        }
+    }
+}
+
+// 1 when the vector-ALU stem kernel runs this layer: 32 stem channels (its chunks per image = icap_stem_dwconv_chunks)
+int stem_dwconv_valu_supported(int C) { return C == SV_C; }
+
+// x: planar fp32 image [B][3][img_h][img_w]; wk: the stem weights k-major, [27][C] with k = (kh * 3 + kw) * 3 + input channel
+int stem_dwconv_valu_f32(const float* x, const float* wk, const float* ss, const float* sb, const float* wd, const float* ds,
+                         const float* db, float* y, float* partial, int B, int img_h, int img_w, int Hs, int Ws, int C,
+                         int stem_pad_t, int stem_pad_l, int pad_t, int pad_l, int Ho, int Wo, hipStream_t st) {
+    if (!x || !wk || !wd || !y || B <= 0 || img_h <= 0 || img_w <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || stem_pad_t < 0 ||
+        stem_pad_l < 0 || pad_t < 0 || pad_l < 0) {
+        set_error("stem_dwconv_valu: bad arguments");
+        return ICAP_ERR_ARG;
+    }
+    if (C != SV_C) { set_error("stem_dwconv_valu: C=%d, the kernel is built for %d stem channels", C, SV_C); return ICAP_ERR_ARG; }
+    if (pad_t > 1 || pad_l > 1) { set_error("stem_dwconv_valu: depthwise padding %d / %d exceeds the tile's halo of 1", pad_t, pad_l); return ICAP_ERR_ARG; }
+    if ((long long)(Hs - 1) * 2 - stem_pad_t >= img_h || (long long)(Ws - 1) * 2 - stem_pad_l >= img_w ||
+        (long long)(Ho - 1) - pad_t >= Hs || (long long)(Wo - 1) - pad_l >= Ws) {
+        set_error("stem_dwconv_valu: output sizes do not fit the image");
+        return ICAP_ERR_ARG;
+    }
+    if (!aligned16(x) || !aligned16(wk) || !aligned16(wd) || !aligned16(y) || (partial && !aligned16(partial)) || (ss && !aligned16(ss)) ||
+        (sb && !aligned16(sb)) || (ds && !aligned16(ds)) || (db && !aligned16(db))) {
+        set_error("stem_dwconv_valu: pointers must be 16-byte aligned");
+        return ICAP_ERR_ALIGN;
+    }
+    if (B > 65535) { set_error("stem_dwconv_valu: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
+    const int tiles_w = (Wo + SV_TW - 1) / SV_TW;
+    const int ntiles = ((Ho + SV_TH - 1) / SV_TH) * tiles_w;
+    hipLaunchKernelGGL(stem_dw_valu_kernel, dim3(ntiles, B), dim3(256), 0, st, x, wk, ss, sb, wd, ds, db, y, partial, img_h, img_w, Hs, Ws,
+                       stem_pad_t, stem_pad_l, pad_t, pad_l, Ho, Wo, tiles_w);
+    return launch_status("stem_dwconv_valu");
+}
+
+}  // namespace icap

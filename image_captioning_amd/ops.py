@@ -642,10 +642,17 @@ def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, k
 
 
 STEM_NCHW = True       # fp32 modes: the fused stem kernel reads the planar NCHW image directly (False: interleave + pad pass first)
+STEM_VALU = True       # ... and, given the k-major stem filter (w_stem_k), runs on the vector-ALU kernel (icap_stem_dwconv_valu_f32)
+
+
+def stem_weight_k(w_stem4: torch.Tensor) -> torch.Tensor:
+    """[C,3,3,4] kernel-layout stem filter (fourth input channel zero) -> [27, C], k = (kh * 3 + kw) * 3 + input channel."""
+    Cc = w_stem4.shape[0]
+    return w_stem4[..., :3].reshape(Cc, 27).t().contiguous()
 
 
 def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, stem_pad=(0, 1, 0, 1), pad=(1, 1, 1, 1), want_partial=False,
-                  out_bf16=False, nchw=False):
+                  out_bf16=False, nchw=False, w_stem_k=None):
     """x [B,H,W,4] (image, channels padded to 4) - or, with nchw=True, the planar fp32 image [B,3,H,W] as the reference hands it
     over (fp32 modes only) -, w_stem [C,3,3,4], w_dw [9, C] ->
     (swish(bn(dw3x3(swish(bn(conv3x3 stride 2 (x)))))), partial): EfficientNet stem + block 0's depthwise convolution."""
@@ -676,6 +683,10 @@ def stem_dwconv2d(x, w_stem, stem_scale, stem_bias, w_dw, dw_scale, dw_bias, *, 
         raise IcapError("stem_dwconv2d: the planar image is taken in the fp32 modes only")
     if bf16:
         N.check(lib.icap_stem_dwconv_bf16_f32(*head, _ck(y, "y", ydt), int(out_bf16), *tail), "stem_dwconv2d")
+    elif nchw and STEM_VALU and w_stem_k is not None and lib.icap_stem_dwconv_valu_supported(Cc):
+        if tuple(w_stem_k.shape) != (27, Cc):
+            raise IcapError("stem_dwconv2d: w_stem_k must be [27, C]")
+        N.check(lib.icap_stem_dwconv_valu_f32(head[0], _ck(w_stem_k, "w_stem_k"), *head[2:], _ck(y, "y"), *tail), "stem_dwconv2d")
     elif nchw:
         N.check(lib.icap_stem_dwconv_nchw_f32(*head, _ck(y, "y"), *tail), "stem_dwconv2d")
     else:

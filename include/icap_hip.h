@@ -132,6 +132,16 @@ int icap_stem_dwconv_nchw_f32(const float* x, const float* w_stem, const float* 
                               const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial, int B,
                               int img_h, int img_w, int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l,
                               int Ho, int Wo, void* stream);
+/* The same layer pair on the vector ALUs alone, for C = 32 stem channels (icap_stem_dwconv_valu_supported): a thread owns one
+ * stem pixel and all channels, the stem weights reach the multiply-adds as scalar operands, the depthwise stage slides over
+ * the tile in LDS.  x planar NCHW fp32 as in icap_stem_dwconv_nchw_f32; w_stem_k is the stem filter k-major, [27][C] with
+ * k = (kh * 3 + kw) * 3 + input channel (the transpose of the reference's [C][3][3][3] weight).  Same result up to the order
+ * of the fp32 sums. */
+int icap_stem_dwconv_valu_supported(int C);
+int icap_stem_dwconv_valu_f32(const float* x, const float* w_stem_k, const float* stem_scale, const float* stem_bias,
+                              const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* partial, int B,
+                              int img_h, int img_w, int Hs, int Ws, int C, int stem_pad_t, int stem_pad_l, int pad_t, int pad_l,
+                              int Ho, int Wo, void* stream);
 int icap_stem_dwconv_chunks(int Ho, int Wo, int C);
 
 /* icap_expand_dwconv_f32 with its expand GEMM as fp32-ACCURATE products on the bf16 matrix cores (exact three-way bf16

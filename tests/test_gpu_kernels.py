@@ -184,6 +184,12 @@ def test_fused_stem_dwconv(H, W):
     y2, part2 = ops.stem_dwconv2d(x.to(d), ws4.to(d), ss.to(d), sb.to(d), wd.view(C, 9).t().contiguous().to(d), dsc.to(d), dbi.to(d),
                                   stem_pad=sp, pad=(1, 1, 1, 1), want_partial=True, nchw=True)
     assert torch.equal(y2, y) and torch.equal(part2, part)
+    # the vector-ALU kernel on the planar image and the k-major filter (icap_stem_dwconv_valu_f32): other order of the fp32 sums
+    y3, part3 = ops.stem_dwconv2d(x.to(d), ws4.to(d), ss.to(d), sb.to(d), wd.view(C, 9).t().contiguous().to(d), dsc.to(d), dbi.to(d),
+                                  stem_pad=sp, pad=(1, 1, 1, 1), want_partial=True, nchw=True, w_stem_k=ops.stem_weight_k(ws4.to(d)))
+    assert not torch.equal(y3, y)                                # it is the other kernel
+    close(y3.permute(0, 3, 1, 2), ref, what="stem+dwconv (vector ALU)")
+    close(part3.sum(1) / (ref.shape[2] * ref.shape[3]), ref.mean((2, 3)), what="stem+dwconv (vector ALU) partial pool")
 
 
 def test_pools():

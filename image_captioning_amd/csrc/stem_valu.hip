@@ -10,6 +10,7 @@
 //   * depthwise phase: a thread owns a strip of 7 output pixels x 4 channels, slides over the 3 x 9 window of LDS rows,
 //     applies BN + swish, stores 16 bytes per pixel (eight lanes = one pixel's 128-byte line) and adds up its outputs for
 //     the per-tile channel sums.
+#include <type_traits>
 #include "common.hpp"
 
 namespace icap {
@@ -91,20 +92,30 @@ __global__ __launch_bounds__(256) void stem_dw_valu_kernel(const float* __restri
         const sv_f32x2* ss2 = reinterpret_cast<const sv_f32x2*>(ss);
         const sv_f32x2* sb2 = reinterpret_cast<const sv_f32x2*>(sb);
         float* erow = E + tid * SV_LDE;
+        const float keep = inside ? 1.f : 0.f;
+        // BN + swish + store; one uniform branch on "both BN vectors given" (the usual case) instead of two per channel pair
+        auto finish = [&](auto both) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c4 = 0; c4 < SV_C / 4; ++c4) {
-            sv_f32x4 o;
+            for (int c4 = 0; c4 < SV_C / 4; ++c4) {
+                sv_f32x4 o;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c2 = 2 * c4 + h;
-                sv_f32x2 v = acc[c2];
-                if (ss) v = v * ss2[c2];
-                if (sb) v = v + sb2[c2];
-                o[2 * h] = inside ? v[0] * sigmoid_fast(v[0]) : 0.f;
-                o[2 * h + 1] = inside ? v[1] * sigmoid_fast(v[1]) : 0.f;
+                for (int h = 0; h < 2; ++h) {
+                    const int c2 = 2 * c4 + h;
+                    sv_f32x2 v = acc[c2];
+                    if constexpr (decltype(both)::value) {
+                        v = __builtin_elementwise_fma(v, ss2[c2], sb2[c2]);
+                    } else {
+                        if (ss) v = v * ss2[c2];
+                        if (sb) v = v + sb2[c2];
+                    }
+                    o[2 * h] = v[0] * sigmoid_fast(v[0]) * keep;         // a multiply, not a branch around the transcendentals
+                    o[2 * h + 1] = v[1] * sigmoid_fast(v[1]) * keep;
+                }
+                *reinterpret_cast<sv_f32x4*>(erow + 4 * c4) = o;
             }
-            *reinterpret_cast<sv_f32x4*>(erow + 4 * c4) = o;
-        }
+        };
+        if (ss && sb) finish(std::true_type{});
+        else finish(std::false_type{});
     }
     __syncthreads();
 
@@ -140,10 +151,10 @@ __global__ __launch_bounds__(256) void stem_dw_valu_kernel(const float* __restri
             sv_f32x4 v = o[j] * sc + bi;
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] = v[t] * sigmoid_fast(v[t]);
-            if (ho < Ho && wo < Wo) {
-                *reinterpret_cast<sv_f32x4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * SV_C + 4 * q) = v;
-                sum += v;
-            }
+            const bool valid = ho < Ho && wo < Wo;
+            if (valid) *reinterpret_cast<sv_f32x4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * SV_C + 4 * q) = v;
+            const float m = valid ? 1.f : 0.f;
+            sum += v * m;
         }
     }
     if (partial) {

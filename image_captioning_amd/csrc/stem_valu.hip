@@ -1,6 +1,7 @@
 // EfficientNet-B0 stem (3x3 stride-2 convolution of the planar fp32 image, folded BN, swish) fused with block 0's depthwise
 // 3x3 stride-1 convolution (+ folded BN + swish + the squeeze-excite partial sums), on the vector ALUs alone:
-//   * the 33 x 33 x 3 image patch under the tile is fetched into LDS in one go (every load of the tile in flight at once);
+//   * the 33 x 33 x 3 image patch under the tile is fetched into LDS in one go (every load of the tile in flight at once; a
+//     wave-load takes two patch rows, so the addressing is a handful of instructions per load);
 //   * a thread owns ONE stem pixel of the tile's 16 x 16 stem region (the 14 x 14 output tile + the depthwise halo) and all
 //     32 channels: it reads its 27 image values from the patch tap by tap, the weights w[k][c] are the same for every lane, so they come
 //     through the scalar cache as instruction operands, and the 864 multiply-adds are packed two channels per instruction;
@@ -19,6 +20,13 @@ typedef float sv_f32x2 __attribute__((ext_vector_type(2)));
 typedef float sv_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SV_C = 32, SV_TH = 14, SV_TW = 14, SV_EH = SV_TH + 2, SV_EW = SV_TW + 2, SV_LDE = SV_C + 4, SV_SW = 7;
+// swish of two values with packed arithmetic around the four transcendentals
+__device__ __forceinline__ sv_f32x2 sv_swish2(sv_f32x2 v) {
+    const sv_f32x2 t = v * sv_f32x2{-1.4426950408889634f, -1.4426950408889634f};
+    const sv_f32x2 d = sv_f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + sv_f32x2{1.f, 1.f};
+    return v * sv_f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+
 constexpr int SV_PH = 2 * SV_EH + 1, SV_PW = 2 * SV_EW + 1, SV_PP = SV_PW + 1;     // image patch rows / columns / row pitch
 static_assert(SV_EH * SV_EW == 256, "one thread per stem pixel of the tile's region");
 
@@ -42,25 +50,44 @@ __global__ __launch_bounds__(256) void stem_dw_valu_kernel(const float* __restri
         const size_t plane = (size_t)img_h * img_w;
         const float* xb = x + (size_t)b * 3 * plane;
         const int ih0 = (ho0 - pad_t) * 2 - stem_pad_t, iw0 = (wo0 - pad_l) * 2 - stem_pad_l;
-        constexpr int NEL = 3 * SV_PH * SV_PW, PER = (NEL + 255) / 256;
-        float v[PER];
+        // columns 0 .. 31: a wave-load takes two patch rows (lanes 0-31 | 32-63), the four waves share a plane's 17 row pairs;
+        // 32-bit element offsets from the image's first plane (an image has far fewer than 2^31 elements)
+        const int pc = lane & 31, half = lane >> 5;
+        const int iw = iw0 + pc;
+        const bool col_ok = (unsigned)iw < (unsigned)img_w;
+        const int plane_i = img_h * img_w;
+        float v[3][5];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = tid + 256 * i;
-            const int pl = e / (SV_PH * SV_PW), rem = e - pl * (SV_PH * SV_PW);
-            const int pr = rem / SV_PW, pc = rem - pr * SV_PW;
-            const int ih = ih0 + pr, iw = iw0 + pc;
-            const bool ok = e < NEL && (unsigned)ih < (unsigned)img_h && (unsigned)iw < (unsigned)img_w;
-            const float t = xb[ok ? pl * plane + (size_t)ih * img_w + iw : 0];       // a select on the address, never a branch
-            v[i] = ok ? t : 0.f;
-        }
+        for (int jj = 0; jj < 5; ++jj) {
+            const int pr = 2 * (wave + 4 * jj) + half;
+            const int ih = ih0 + pr;
+            const bool ok = col_ok && pr < SV_PH && (unsigned)ih < (unsigned)img_h;
+            const int off = ok ? ih * img_w + iw : 0;                      // a select on the address, never a branch
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = tid + 256 * i;
-            const int pl = e / (SV_PH * SV_PW), rem = e - pl * (SV_PH * SV_PW);
-            const int pr = rem / SV_PW, pc = rem - pr * SV_PW;
-            if (e < NEL) X[(pl * SV_PH + pr) * SV_PP + pc] = v[i];
+            for (int pl = 0; pl < 3; ++pl) {
+                const float t = xb[off + (ok ? pl * plane_i : 0)];
+                v[pl][jj] = ok ? t : 0.f;
+            }
         }
+        // column 32: one element per thread
+        const int lpl = tid / SV_PH, lpr = tid - lpl * SV_PH;
+        float vl;
+        {
+            const int ih = ih0 + lpr, iwl = iw0 + SV_PW - 1;
+            const bool ok = tid < 3 * SV_PH && (unsigned)ih < (unsigned)img_h && (unsigned)iwl < (unsigned)img_w;
+            const float t = xb[ok ? lpl * plane_i + ih * img_w + iwl : 0];
+            vl = ok ? t : 0.f;
+        }
+        float* xrow = X + (2 * wave + half) * SV_PP + pc;
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+            const int pr = 2 * (wave + 4 * jj) + half;
+            if (pr < SV_PH) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xrow[(pl * SV_PH + 8 * jj) * SV_PP] = v[pl][jj];
+            }
+        }
+        if (tid < 3 * SV_PH) X[(lpl * SV_PH + lpr) * SV_PP + SV_PW - 1] = vl;
     }
     __syncthreads();
 
@@ -75,12 +102,17 @@ __global__ __launch_bounds__(256) void stem_dw_valu_kernel(const float* __restri
         const sv_f32x2* wk2 = reinterpret_cast<const sv_f32x2*>(wk);              // [27][16] channel pairs, uniform addresses
         const float* xp = X + (2 * sy) * SV_PP + 2 * sx;
         // one filter tap per trip (not unrolled: the 96 weights of a tap fit the scalar registers, all 864 would not)
+        float xn[3];
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) xn[ci] = xp[ci * SV_PH * SV_PP];
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - kh * 3;
-            float xv[3];
+            // the next tap's three values are read while this tap multiplies (the last trip re-reads tap 8)
+            const float xv[3] = {xn[0], xn[1], xn[2]};
+            const int tn = tap < 8 ? tap + 1 : 8;
+            const int kh = tn / 3, kw = tn - kh * 3;
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) xv[ci] = xp[(ci * SV_PH + kh) * SV_PP + kw];
+            for (int ci = 0; ci < 3; ++ci) xn[ci] = xp[(ci * SV_PH + kh) * SV_PP + kw];
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
                 const sv_f32x2 xk = {xv[ci], xv[ci]};
@@ -108,8 +140,9 @@ __global__ __launch_bounds__(256) void stem_dw_valu_kernel(const float* __restri
                         if (ss) v = v * ss2[c2];
                         if (sb) v = v + sb2[c2];
                     }
-                    o[2 * h] = v[0] * sigmoid_fast(v[0]) * keep;         // a multiply, not a branch around the transcendentals
-                    o[2 * h + 1] = v[1] * sigmoid_fast(v[1]) * keep;
+                    v = sv_swish2(v * sv_f32x2{keep, keep});          // masked by a multiply, not a branch around the transcendentals
+                    o[2 * h] = v[0];
+                    o[2 * h + 1] = v[1];
                 }
                 *reinterpret_cast<sv_f32x4*>(erow + 4 * c4) = o;
             }
@@ -145,16 +178,28 @@ __global__ __launch_bounds__(256) void stem_dw_valu_kernel(const float* __restri
         if (dsc) sc = *reinterpret_cast<const sv_f32x4*>(dsc + 4 * q);
         if (dbi) bi = *reinterpret_cast<const sv_f32x4*>(dbi + 4 * q);
         const int ho = ho0 + r;
+        if (ho0 + SV_TH <= Ho && wo0 + SV_TW <= Wo) {          // whole tile inside the output (uniform): no masks
+            float* yrow = y + (((size_t)b * Ho + ho) * Wo + wo0 + col0) * SV_C + 4 * q;
 #pragma unroll
-        for (int j = 0; j < SV_SW; ++j) {
-            const int wo = wo0 + col0 + j;
-            sv_f32x4 v = o[j] * sc + bi;
+            for (int j = 0; j < SV_SW; ++j) {
+                const sv_f32x4 t = o[j] * sc + bi;
+                const sv_f32x2 lo = sv_swish2(sv_f32x2{t[0], t[1]}), hi = sv_swish2(sv_f32x2{t[2], t[3]});
+                const sv_f32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+                *reinterpret_cast<sv_f32x4*>(yrow + (size_t)j * SV_C) = v;
+                sum += v;
+            }
+        } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = v[t] * sigmoid_fast(v[t]);
-            const bool valid = ho < Ho && wo < Wo;
-            if (valid) *reinterpret_cast<sv_f32x4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * SV_C + 4 * q) = v;
-            const float m = valid ? 1.f : 0.f;
-            sum += v * m;
+            for (int j = 0; j < SV_SW; ++j) {
+                const int wo = wo0 + col0 + j;
+                sv_f32x4 v = o[j] * sc + bi;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = v[t] * sigmoid_fast(v[t]);
+                const bool valid = ho < Ho && wo < Wo;
+                if (valid) *reinterpret_cast<sv_f32x4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * SV_C + 4 * q) = v;
+                const float m = valid ? 1.f : 0.f;
+                sum += v * m;
+            }
         }
     }
     if (partial) {

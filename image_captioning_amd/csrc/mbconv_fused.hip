@@ -22,9 +22,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 xd_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 xd_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
+typedef float xd_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XD_CC = 32;            // expanded channels per chunk (one MFMA column block)
 constexpr int XD_LDE = XD_CC + 4;    // padded row of E (16-byte aligned rows, consecutive pixels start 4 banks apart)
+
+// x * sigmoid(x) on a pair: the multiplies and the add as packed fp32 instructions, exp2 and rcp per element
+__device__ __forceinline__ xd_f32x2 xd_swish2(xd_f32x2 v) {
+    const xd_f32x2 nk2 = {-1.4426950408889634f, -1.4426950408889634f}, one2 = {1.f, 1.f};
+    xd_f32x2 t = v * nk2;
+    t.x = __builtin_amdgcn_exp2f(t.x); t.y = __builtin_amdgcn_exp2f(t.y);
+    t = t + one2;
+    t.x = __builtin_amdgcn_rcpf(t.x); t.y = __builtin_amdgcn_rcpf(t.y);
+    return v * t;
+}
 
 // Workgroups whose LDS footprint fits a CU three times are compiled for three waves per SIMD, the others for two.
 template <int KS, int S, int TH, int TW, bool WIDE = false>
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     // ---- A fragments: this wave's pixels, all CIN input channels split over the two lane halves ----
     // Nothing here consumes a loaded value (a consumer would wait for the load where it is issued): pixels outside the
     // image read a valid dummy address and their rows are zeroed after the MFMAs; only the stem's image-border taps need
-    // true zeros, applied right before the fragment's first use (tapmask bit j: tap j of this lane is real).
+    // true zeros, applied after the first chunk's parameter loads have been issued (tapmask bit j: tap j of this lane is real).
     float af[NRB][KH2];
     unsigned rowmask[NRB], tapmask[NRB];
 #pragma unroll
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
                 tapmask[i] |= (tok || !ok || tap >= 9) ? (1u << j) : 0u;
             }
         } else {
-            const float* src = ok ? x + (((size_t)b * H + hi) * W + wi) * CIN + lh * KH2 : x;
+            const float* src = x + (size_t)b * H * W * CIN + (ok ? (unsigned)((hi * W + wi) * CIN + lh * KH2) : 0u);
 #pragma unroll
             for (int k = 0; k < KH2; k += 4) {
                 const float4 v = *reinterpret_cast<const float4*>(src + k);
@@ -124,7 +135,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     const int nchunks = (Cexp + XD_CC - 1) / XD_CC;
     const int ch_end = min(nchunks, ((int)blockIdx.z + 1) * cpg);
     const int q = tid & 7, sidx = tid >> 3;
-    const size_t ybase = (size_t)b * Ho * Wo;
+    // per-image bases are wave-uniform (scalar registers); what a thread adds fits 32 bits (the host checks the image size)
+    const size_t ybase = (size_t)b * Ho * Wo * Cexp;
 
     // Per-chunk parameters are fetched one chunk ahead so that no phase waits for a global load it has just issued; the
     // fetched values are consumed (scaled, stored to LDS) only when the chunk that fetched them hands over.
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
         const int cn = ch * XD_CC + lr;
         const bool cok = cn < Cexp;
         constexpr int WLD = STEM ? 36 : CIN;      // floats per weight row in memory
-        const float* wsrc = we + (size_t)(cok ? cn : 0) * WLD + lh * KH2;
+        const float* wsrc = we + (unsigned)((cok ? cn : 0) * WLD + lh * KH2);
         s_ = (cok && es) ? es[cn] : (cok ? 1.f : 0.f);
         b_ = (cok && eb) ? eb[cn] : 0.f;
 #pragma unroll
@@ -218,6 +230,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
         if constexpr (BF16) pack_planes(bf, b16);
         if (wrow < WROWS) Wl[ch_begin & 1][wrow][q] = fold_dw(wv, ws4);
     }
+    // The A fragments take their final form once, here (after the first chunk's parameter loads have been issued): the
+    // stem's border taps become zeros, and for the bf16 products the pixels are packed (and split) so that the chunk loop
+    // holds only the packed planes.
+#pragma unroll
+    for (int i = 0; i < NRB; ++i) {
+        if (wave + 4 * i < MB) {
+            if constexpr (STEM) {
+                if (__any(tapmask[i] != 0x1f)) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j)
+                        if (!((tapmask[i] >> j) & 1u)) { af[i][4 * j] = 0.f; af[i][4 * j + 1] = 0.f; af[i][4 * j + 2] = 0.f; af[i][4 * j + 3] = 0.f; }
+                }
+            }
+            if constexpr (BF16) pack_planes(af[i], a16[i]);
+        }
+    }
 
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int c0 = ch * XD_CC;
@@ -232,18 +260,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
             for (int i = 0; i < NRB; ++i) {
                 const int rb = wave + 4 * i;
                 if (rb < MB) {
-                    if constexpr (STEM) {
-                        if (__any(tapmask[i] != 0x1f)) {
-#pragma unroll
-                            for (int j = 0; j < 5; ++j)
-                                if (!((tapmask[i] >> j) & 1u)) { af[i][4 * j] = 0.f; af[i][4 * j + 1] = 0.f; af[i][4 * j + 2] = 0.f; af[i][4 * j + 3] = 0.f; }
-                        }
-                    }
-                    f32x16 acc;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = bi;
+                    // the accumulator starts at zero (no register initialisation: the first MFMA takes the constant) and
+                    // the folded-BN bias joins in the packed epilogue
+                    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     if constexpr (BF16) {
-                        if (ch == ch_begin) pack_planes(af[i], a16[i]);
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) {
                             if constexpr (NPL == 3) {   // smallest terms first: (a plane, b plane) with plane sum <= 2
@@ -260,31 +280,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
 #pragma unroll
                         for (int s = 0; s < KH2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[s], acc, 0, 0, 0);
                     }
-                    // swish stage by stage over all 16 accumulators, so that no exp2 / rcp result is needed right
-                    // after it is issued
+                    // bias + swish on accumulator pairs (packed fp32 instructions), stage by stage over all eight pairs so
+                    // that no exp2 / rcp result is needed right after it is issued
+                    const xd_f32x2 bi2 = {bi, bi}, nk2 = {-1.4426950408889634f, -1.4426950408889634f}, one2 = {1.f, 1.f};
                     float r[16];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) r[e] = __builtin_amdgcn_exp2f(acc[e] * -1.4426950408889634f);
+                    for (int hf = 0; hf < 2; ++hf) {   // eight accumulators at a time: four live temporaries
+                        xd_f32x2 z[4], t[4];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) r[e] = __builtin_amdgcn_rcpf(r[e] + 1.f);
+                        for (int e = 0; e < 4; ++e) { const xd_f32x2 a2 = {acc[8 * hf + 2 * e], acc[8 * hf + 2 * e + 1]}; z[e] = a2 + bi2; }
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) r[e] *= acc[e];
+                        for (int e = 0; e < 4; ++e) t[e] = z[e] * nk2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { t[e].x = __builtin_amdgcn_exp2f(t[e].x); t[e].y = __builtin_amdgcn_exp2f(t[e].y); }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = t[e] + one2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { t[e].x = __builtin_amdgcn_rcpf(t[e].x); t[e].y = __builtin_amdgcn_rcpf(t[e].y); }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const xd_f32x2 o2 = z[e] * t[e]; r[8 * hf + 2 * e] = o2.x; r[8 * hf + 2 * e + 1] = o2.y; }
+                    }
                     float* dst = &E[(rb * 32 + 4 * lh) * XD_LDE + lr];
-                    const unsigned mask = rowmask[i];
-                    if (mask == 0xffffffffu) {     // wave-uniform: no pixel of this row block lies outside the image
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * XD_LDE] = r[e];
-                    } else {
-                        const unsigned lmask = mask >> (4 * lh);
+                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * XD_LDE] = r[e];
+                    // rows of pixels outside the image become zeros (a wave-uniform test: border tiles only): lane (lr, lh)
+                    // clears half lh of row lr with 16-byte writes; a wave's LDS writes keep their order
+                    if (rowmask[i] != 0xffffffffu) {
+                        if (!((rowmask[i] >> lr) & 1u)) {
+                            float4* zrow = reinterpret_cast<float4*>(&E[(rb * 32 + lr) * XD_LDE + lh * 16]);
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            dst[((e & 3) + 8 * (e >> 2)) * XD_LDE] = ((lmask >> ((e & 3) + 8 * (e >> 2))) & 1u) ? r[e] : 0.f;
+                            for (int j = 0; j < 4; ++j) zrow[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
                     }
                 }
             }
         }
         if (wrow < WROWS) Wl[(ch + 1) & 1][wrow][q] = fold_dw(wln, wsn);
+        // the next chunk's B fragments take their place now, not at the end of the chunk: a wait for their loads there
+        // would also wait for the depthwise phase's stores, which have only just been issued
+        fold_b(bf, bfn, scn);
+        if constexpr (BF16) pack_planes(bf, b16);
+        bi = bin;
         __syncthreads();
 
         // ---- depthwise over E ----
@@ -328,16 +364,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
                 for (int o = 0; o < SW; ++o) {
                     const int wl = so + o, wo = wo0 + wl;
                     if (wl < TW && ho < Ho && wo < Wo) {
-                        float4 u = acc[o];
-                        u.x *= sigmoid_fast(u.x); u.y *= sigmoid_fast(u.y); u.z *= sigmoid_fast(u.z); u.w *= sigmoid_fast(u.w);
-                        const size_t yo = (ybase + (size_t)ho * Wo + wo) * Cexp + c;
+                        const xd_f32x2 ulo = xd_swish2(xd_f32x2{acc[o].x, acc[o].y}), uhi = xd_swish2(xd_f32x2{acc[o].z, acc[o].w});
+                        const float4 u = make_float4(ulo.x, ulo.y, uhi.x, uhi.y);
+                        const size_t yo = ybase + (unsigned)((ho * Wo + wo) * Cexp + c);
                         if (out16) {   // bf16 output tensor (round to nearest even): half the store traffic
                             const xd_f32x2 lo = {u.x, u.y}, hi = {u.z, u.w};
                             *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + yo) =
                                 make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, xd_bf16x2)),
                                            __builtin_bit_cast(unsigned, __builtin_convertvector(hi, xd_bf16x2)));
                         } else {
-                            *reinterpret_cast<float4*>(y + yo) = u;
+                            // streaming store: the tensor is far larger than the caches and is read next by another kernel
+                            __builtin_nontemporal_store(xd_f32x4{u.x, u.y, u.z, u.w}, reinterpret_cast<xd_f32x4*>(y + yo));
                         }
                         sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
                     }
@@ -360,9 +397,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
             for (int w2 = 1; w2 < 4; ++w2) { t.x += red[w2][tid].x; t.y += red[w2][tid].y; t.z += red[w2][tid].z; t.w += red[w2][tid].w; }
             *reinterpret_cast<float4*>(partial + ((size_t)b * gridDim.x + tile) * Cexp + c) = t;
         }
-        fold_b(bf, bfn, scn);
-        if constexpr (BF16) pack_planes(bf, b16);
-        bi = bin;
     }
 }
 
@@ -426,6 +460,10 @@ int expand_dwconv_f32(const float* x, const float* we, const float* es, const fl
         return ICAP_ERR_ALIGN;
     }
     if (B > 65535) { set_error("expand_dwconv: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
+    if ((long long)H * W * Cin >= (1ll << 31) || (long long)Ho * Wo * Cexp >= (1ll << 31) || (long long)Cexp * (Cin > KS * KS ? Cin : KS * KS) >= (1ll << 31)) {
+        set_error("expand_dwconv: one image's input, output and the weights must each stay below 2^31 elements");
+        return ICAP_ERR_LIMIT;
+    }
     const int tiles_w = (Wo + c->tw - 1) / c->tw;
     const int ntiles = ((Ho + c->th - 1) / c->th) * tiles_w;
     const int nchunks = (Cexp + XD_CC - 1) / XD_CC;
@@ -482,6 +520,7 @@ int stem_dwconv_f32(const float* x, const float* ws, const float* ss, const floa
         return ICAP_ERR_ALIGN;
     }
     if (B > 65535) { set_error("stem_dwconv: B=%d exceeds 65535", B); return ICAP_ERR_LIMIT; }
+    if ((long long)Ho * Wo * C >= (1ll << 31)) { set_error("stem_dwconv: one image's output must stay below 2^31 elements"); return ICAP_ERR_LIMIT; }
     const int out16 = ((bf16 >> 1) & 1) | ((bf16 >> 3) & 1) << 1;     // bf16: bit 0 = bf16 products, bit 1 = bf16 output tensor, bit 3 = x is planar NCHW
     bf16 &= 1;
     const int tiles_w = (Wo + STEM_TW - 1) / STEM_TW;

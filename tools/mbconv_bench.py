@@ -11,6 +11,8 @@ LAYERS = [(16, 96, 112, 3, 2, (0, 1, 0, 1)), (24, 144, 56, 3, 1, (1, 1, 1, 1)), 
           (40, 240, 28, 5, 1, (2, 2, 2, 2)), (40, 240, 28, 3, 2, (0, 1, 0, 1)),
           (80, 480, 14, 3, 1, (1, 1, 1, 1)), (80, 480, 14, 5, 1, (2, 2, 2, 2)), (112, 672, 14, 5, 1, (2, 2, 2, 2)),
           (192, 1152, 7, 5, 1, (2, 2, 2, 2)), (192, 1152, 7, 3, 1, (1, 1, 1, 1))]
+if os.environ.get("ICAP_MB_EARLY"):
+    LAYERS = LAYERS[:5]
 if os.environ.get("ICAP_MB_LATE"):
     LAYERS = LAYERS[5:]
 d = torch.device("cuda:0")

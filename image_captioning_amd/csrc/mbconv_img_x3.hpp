@@ -24,6 +24,14 @@
 
 namespace icap {
 
+// 16-byte streaming store for the 14 x 14 layers: their expanded tensor (0.4-0.5 GB at B = 1024) is larger than the caches and is
+// read next by another kernel; the 7 x 7 layers' (0.23 GB) is not, and plain stores are faster there
+typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void x3_stream_store(float* dst, const float4& v) {
+    __builtin_nontemporal_store(x3_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<x3_f32x4*>(dst));
+}
+
+
 typedef float x3_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 x3_bf16x2 __attribute__((ext_vector_type(2)));
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void expand_dw_img_x3_kernel(const float* _
                 float* dst = y + (((size_t)(img0 + timg) * PX + trow * HW) * Cexp + (cb < Cexp ? cb : 0));
                 if (st_ok) {
 #pragma unroll
-                    for (int c2 = 0; c2 < HW; ++c2) *reinterpret_cast<float4*>(dst + (size_t)c2 * Cexp) = o[c2];
+                    for (int c2 = 0; c2 < HW; ++c2) *reinterpret_cast<float4*>(dst + (size_t)c2 * Cexp) = o[c2];   // 7 x 7 layers: the tensor fits the last-level cache, plain stores
                 }
                 if (tvalid) *reinterpret_cast<float4*>(&red[task][q * 4]) = ps;
             }
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
                 float* dst = y + (((size_t)(img_ok ? img0 : 0) * PX + trow * HW) * Cexp + (cb < Cexp ? cb : 0));
                 if (st_ok) {
 #pragma unroll
-                    for (int l2 = 0; l2 < HALF; ++l2) *reinterpret_cast<float4*>(dst + (size_t)ecol(l2) * Cexp) = o[l2];
+                    for (int l2 = 0; l2 < HALF; ++l2) x3_stream_store(dst + (size_t)ecol(l2) * Cexp, o[l2]);
                 }
                 if (tvalid) *reinterpret_cast<float4*>(&red[task][q * 4]) = ps;
             }

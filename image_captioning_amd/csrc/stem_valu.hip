@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void stem_dw_valu_kernel(const float* __restri
                 const sv_f32x4 t = o[j] * sc + bi;
                 const sv_f32x2 lo = sv_swish2(sv_f32x2{t[0], t[1]}), hi = sv_swish2(sv_f32x2{t[2], t[3]});
                 const sv_f32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-                *reinterpret_cast<sv_f32x4*>(yrow + (size_t)j * SV_C) = v;
+                __builtin_nontemporal_store(v, reinterpret_cast<sv_f32x4*>(yrow + (size_t)j * SV_C));   // streaming: read next by another kernel
                 sum += v;
             }
         } else {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void stem_dw_valu_kernel(const float* __restri
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = v[t] * sigmoid_fast(v[t]);
                 const bool valid = ho < Ho && wo < Wo;
-                if (valid) *reinterpret_cast<sv_f32x4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * SV_C + 4 * q) = v;
+                if (valid) __builtin_nontemporal_store(v, reinterpret_cast<sv_f32x4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * SV_C + 4 * q));
                 const float m = valid ? 1.f : 0.f;
                 sum += v * m;
             }

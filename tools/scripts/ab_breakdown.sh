@@ -1,4 +1,5 @@
-# Same-box A/B of the whole captioning step: per-launch breakdown with the library in the tree and with tools/ab/libicap_hip_old.so
+# Same-box A/B of the whole captioning step: bench.py --breakdown with the library in the tree, with tools/ab/libicap_hip_old.so
+# (a build of the revision to compare against: check it out, make, copy the .so there), and with the tree's again
 set -e
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/ab; mkdir -p $O

@@ -1,4 +1,5 @@
-# Same-box A/B of the fused MBConv layers: the library in the tree (wave-specialised and single-role kernels) against tools/ab/libicap_hip_old.so
+# Same-box A/B of the fused MBConv layers: GPU tests, then tools/mbconv_bench.py with the library in the tree, with
+# tools/ab/libicap_hip_old.so (a build of the revision to compare against: check it out, make, copy the .so there), and with the tree's again
 set -e
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/ab; mkdir -p $O

@@ -73,6 +73,8 @@ SIGNATURES = {
     "icap_expand_dwconv_img_x3_we_bytes": (_ll, [_i] * 5),
     "icap_expand_dwconv_img_x3_pack": (_i, [_p, _p] + [_i] * 5 + [_p]),
     "icap_expand_dwconv_img_x3_f32": (_i, [_p] * 9 + [_i] * 8 + [_p]),
+    "icap_expand_dwconv_img_x3_s2_supported": (_i, [_i] * 7),
+    "icap_expand_dwconv_img_x3_s2_f32": (_i, [_p] * 9 + [_i] * 8 + [_p]),
     "icap_stem_dwconv_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),
     "icap_stem_dwconv_nchw_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),
     "icap_stem_dwconv_valu_f32": (_i, [_p] * 9 + [_i] * 12 + [_p]),

@@ -89,6 +89,9 @@ long long expand_dwconv_img_x3_we_bytes(int, int, int, int, int);
 int expand_dwconv_img_x3_pack(const float*, void*, int, int, int, int, int, hipStream_t);
 int expand_dwconv_img_x3_f32(const float*, const void*, const float*, const float*, const float*, const float*, const float*, float*,
                              float*, int, int, int, int, int, int, int, int, hipStream_t);
+int expand_dwconv_img_x3_s2_supported(int, int, int, int, int, int, int);
+int expand_dwconv_img_x3_s2_f32(const float*, const void*, const float*, const float*, const float*, const float*, const float*, float*,
+                                float*, int, int, int, int, int, int, int, int, hipStream_t);
 int stem_dwconv_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                     float*, int, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int stem_dwconv_chunks(int, int, int);
@@ -384,6 +387,17 @@ int icap_expand_dwconv_img_x3_f32(const float* x, const void* w_packed, const fl
                                   int Cexp, int KS, int pad_t, int pad_l, void* stream) {
     return expand_dwconv_img_x3_f32(x, w_packed, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, y, pooled, B, H, W, Cin, Cexp, KS, pad_t,
                                     pad_l, (hipStream_t)stream);
+}
+
+int icap_expand_dwconv_img_x3_s2_supported(int H, int W, int Cin, int Cexp, int KS, int pad_t, int pad_l) {
+    return expand_dwconv_img_x3_s2_supported(H, W, Cin, Cexp, KS, pad_t, pad_l);
+}
+
+int icap_expand_dwconv_img_x3_s2_f32(const float* x, const void* w_packed, const float* exp_scale, const float* exp_bias, const float* w_dw,
+                                     const float* dw_scale, const float* dw_bias, float* y, float* pooled, int B, int H, int W, int Cin,
+                                     int Cexp, int KS, int pad_t, int pad_l, void* stream) {
+    return expand_dwconv_img_x3_s2_f32(x, w_packed, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, y, pooled, B, H, W, Cin, Cexp, KS, pad_t,
+                                       pad_l, (hipStream_t)stream);
 }
 
 int icap_se_gate_f32(const float* partial, int nchunks, float inv_hw, const float* wr, const float* br, const float* we,

@@ -30,10 +30,18 @@ int expand_dwconv_img_x3_pack(const float* we, void* out, int H, int W, int Cin,
     return launch_status("expand_dwconv pack");
 }
 
-int expand_dwconv_img_x3_f32(const float* x, const void* we3p, const float* es, const float* eb, const float* wd, const float* ds,
-                             const float* db, float* y, float* pooled, int B, int H, int W, int Cin, int Cexp, int KS, int pad_t,
-                             int pad_l, hipStream_t st) {
-    if (!x || !we3p || !wd || !y || B <= 0 || expand_dwconv_img_x3_we_bytes(H, W, Cin, Cexp, KS) == 0 || pad_t != KS / 2 || pad_l != KS / 2) {
+// stride 2 (14 x 14 -> 7 x 7, TF-'same' padding: one row / column of zeros before the image for a 5 x 5 filter): the layer
+// shapes that have a kernel
+int expand_dwconv_img_x3_s2_supported(int H, int W, int Cin, int Cexp, int KS, int pad_t, int pad_l) {
+    return H == 14 && W == 14 && Cin == 112 && KS == 5 && pad_t == 1 && pad_l == 1 && Cexp > 0 && Cexp % 4 == 0;
+}
+
+static int expand_dwconv_img_x3_launch(const float* x, const void* we3p, const float* es, const float* eb, const float* wd, const float* ds,
+                                       const float* db, float* y, float* pooled, int B, int H, int W, int Cin, int Cexp, int KS, int pad_t,
+                                       int pad_l, int stride, hipStream_t st) {
+    const bool shape_ok = stride == 2 ? expand_dwconv_img_x3_s2_supported(H, W, Cin, Cexp, KS, pad_t, pad_l) != 0
+                                      : (expand_dwconv_img_x3_we_bytes(H, W, Cin, Cexp, KS) != 0 && pad_t == KS / 2 && pad_l == KS / 2);
+    if (!x || !we3p || !wd || !y || B <= 0 || !shape_ok) {
         set_error("expand_dwconv (whole image, split products): unsupported layer %dx%d Cin=%d %dx%d pad %d,%d", H, W, Cin, KS, KS, pad_t, pad_l);
         return ICAP_ERR_ARG;
     }
@@ -58,7 +66,10 @@ int expand_dwconv_img_x3_f32(const float* x, const void* we3p, const float* es, 
     // 14 x 14: eight waves, the A planes of the first five K slices in registers (all of them for 80 input channels)
 #define ICAP_X3W8(CIN_, KS_) \
     hipLaunchKernelGGL((expand_dw_img14_w8_kernel<CIN_, KS_, 5>), grid, block8, 0, st, x, wp, es, eb, wd, ds, db, y, pooled, B, Cexp, nchunk, cpg, nsplit)
-    if (Cin == 80 && KS == 3) ICAP_X3W8(80, 3);
+    if (stride == 2)
+        hipLaunchKernelGGL((expand_dw_img14_w8_kernel<112, 5, 5, 2>), grid, block8, 0, st, x, wp, es, eb, wd, ds, db, y, pooled, B, Cexp, nchunk,
+                           cpg, nsplit);
+    else if (Cin == 80 && KS == 3) ICAP_X3W8(80, 3);
     else if (Cin == 80) ICAP_X3W8(80, 5);
     else if (Cin == 112 && KS == 3) ICAP_X3W8(112, 3);
     else if (Cin == 112) ICAP_X3W8(112, 5);
@@ -67,6 +78,19 @@ int expand_dwconv_img_x3_f32(const float* x, const void* we3p, const float* es, 
 #undef ICAP_X3W8
 #undef ICAP_X3
     return launch_status("expand_dwconv (whole image, split products)");
+}
+
+int expand_dwconv_img_x3_f32(const float* x, const void* we3p, const float* es, const float* eb, const float* wd, const float* ds,
+                             const float* db, float* y, float* pooled, int B, int H, int W, int Cin, int Cexp, int KS, int pad_t,
+                             int pad_l, hipStream_t st) {
+    return expand_dwconv_img_x3_launch(x, we3p, es, eb, wd, ds, db, y, pooled, B, H, W, Cin, Cexp, KS, pad_t, pad_l, 1, st);
+}
+
+// y [B][7][7][Cexp]; the packed weights are those of the stride-1 layer of the same shape (expand_dwconv_img_x3_pack)
+int expand_dwconv_img_x3_s2_f32(const float* x, const void* we3p, const float* es, const float* eb, const float* wd, const float* ds,
+                                const float* db, float* y, float* pooled, int B, int H, int W, int Cin, int Cexp, int KS, int pad_t,
+                                int pad_l, hipStream_t st) {
+    return expand_dwconv_img_x3_launch(x, we3p, es, eb, wd, ds, db, y, pooled, B, H, W, Cin, Cexp, KS, pad_t, pad_l, 2, st);
 }
 
 }  // namespace icap

@@ -410,7 +410,12 @@ __global__ __launch_bounds__(256, 1) void expand_dw_img_x3_kernel(const float* _
 // (wave 7's block is empty: it only joins the barriers) and keeps the planes of the first NKR K slices in registers, the
 // rest in LDS (written once, read back by the same wave).  The depthwise tasks are HALF rows (7 outputs): a thread of the
 // right half works on the mirrored row - column 13 - u, tap KS - 1 - j - so both halves run the same instruction stream.
-template <int CIN, int KS, int NKR>
+//
+// STRIDE = 2 (the 14 x 14 -> 7 x 7 block): same GEMM and E tile, TF-'same' padding (PT rows / columns of zeros before the
+// image).  The 49 outputs of a channel quad are spread over the same 28 task slots: wave w owns output row w, its four
+// slots two neighbouring outputs each (the last slot one), over the seven input columns those need; a column outside the
+// image reads a zero row of E instead.
+template <int CIN, int KS, int NKR, int STRIDE = 1>
 __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float* __restrict__ x, const uint4* __restrict__ we3p,
                                                                     const float* __restrict__ es, const float* __restrict__ eb,
                                                                     const float* __restrict__ wd, const float* __restrict__ ds,
@@ -418,7 +423,13 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
                                                                     float* __restrict__ pooled, int B, int Cexp, int nchunk, int cpg,
                                                                     int nsplit) {
     constexpr int HW = 14, PX = HW * HW, NK = CIN / 16, PAD = KS / 2, RPI = HW + 2 * PAD, NCB = 2;
-    constexpr int XCH = 64, ES = XCH, NQ = 16, HALF = 7, NT = 2 * HW, NIN = HALF + PAD;     // ES: see the four-wave kernel
+    constexpr int HO = STRIDE == 2 ? HW / 2 : HW;                                           // output rows = columns
+    constexpr int PT = STRIDE == 2 ? ((HO - 1) * 2 + KS - HW) / 2 : PAD;                    // zero rows / columns before the image
+    constexpr int XCH = 64, ES = XCH, NQ = 16, HALF = 7;                                    // ES: see the four-wave kernel
+    constexpr int NT = 2 * HW;                                                              // depthwise task slots
+    constexpr int NOUT = STRIDE == 2 ? 2 : HALF;                                            // outputs per task
+    constexpr int NIN = STRIDE == 2 ? (NOUT - 1) * 2 + KS : HALF + PAD;                     // input columns per task
+    static_assert(STRIDE == 1 || STRIDE == 2, "stride");
     constexpr int PD = 2;                                   // LDS reads of E in flight ahead of their use
     constexpr int NKL = NK > NKR ? NK - NKR : 0;            // K slices whose A planes live in LDS
     constexpr int WROWS = KS * KS + 2;
@@ -447,7 +458,8 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
     const int q = tid % NQ, slot = tid / NQ;
     const bool tvalid = slot < NT;
     const int task = tvalid ? slot : 0;
-    const int th = task / HW, trow = task - th * HW;        // a wave's four tasks: consecutive rows of one half
+    // stride 1: a wave's four tasks are consecutive rows of one half; stride 2: output row task / 4, outputs 2 * cg, 2 * cg + 1
+    const int th = STRIDE == 2 ? 0 : task / HW, trow = STRIDE == 2 ? task >> 2 : task - th * HW, cg = task & 3;
 
     for (int idx = tid; idx < E_FLOATS / 4; idx += 512) reinterpret_cast<float4*>(E)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -537,30 +549,39 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
 
     // ---- depthwise steps (see the four-wave kernel): item k < KS = filter row k (step 0: taps; step 1 + u: input u of the
     // mirrored half row), item KS = epilogue (step 1 + l: output l; the last step stores)
-    constexpr int ROW_STEPS = NIN + 1, EPI_STEPS = HALF + 1;
-    float4 o[HALF], wr[KS], evq[PD], dsv, dbv, ps;
+    constexpr int ROW_STEPS = NIN + 1, EPI_STEPS = NOUT + 1;
+    float4 o[NOUT], wr[KS], evq[PD], dsv, dbv, ps;
     auto ecol = [&](int u) { return th ? HW - 1 - u : u; };
+    // input u of the task in filter row erow: stride 2 - column 4 * cg - PT + u, or E's first (all-zero) row outside the image
+    auto eload = [&](const float* erow, int u) {
+        if constexpr (STRIDE == 2) {
+            const int col = 4 * cg - PT + u;
+            return *reinterpret_cast<const float4*>((unsigned)col < (unsigned)HW ? erow + col * ES : &E[q * 4]);
+        } else {
+            return *reinterpret_cast<const float4*>(erow + ecol(u) * ES);
+        }
+    };
     auto dw_step = [&](int item, int step, int buf, int chunk) {
         if (item < KS) {
             const int dr = item;
-            const float* erow = &E[((trow + dr) * HW) * ES + q * 4];
+            const float* erow = &E[((STRIDE * trow + dr + PAD - PT) * HW) * ES + q * 4];
             if (step == 0) {
                 if (dr == 0) {
 #pragma unroll
-                    for (int l = 0; l < HALF; ++l) o[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int l = 0; l < NOUT; ++l) o[l] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int j = 0; j < KS; ++j) wr[j] = wds[buf][dr * KS + (th ? KS - 1 - j : j)][q];
 #pragma unroll
-                for (int d = 0; d < PD; ++d) evq[d] = *reinterpret_cast<const float4*>(erow + ecol(d) * ES);
+                for (int d = 0; d < PD; ++d) evq[d] = eload(erow, d);
                 return;
             }
             const int u = step - 1;
             const float4 ev = evq[u % PD];
-            if (u + PD < NIN) evq[u % PD] = *reinterpret_cast<const float4*>(erow + ecol(u + PD) * ES);
+            if (u + PD < NIN) evq[u % PD] = eload(erow, u + PD);
 #pragma unroll
-            for (int l = 0; l < HALF; ++l) {
-                const int j = u - l + PAD;                   // mirrored tap feeding output l from input u
+            for (int l = 0; l < NOUT; ++l) {
+                const int j = STRIDE == 2 ? u - 2 * l : u - l + PAD;   // (mirrored) tap feeding output l from input u
                 if (j >= 0 && j < KS) {
                     o[l].x = fmaf(ev.x, wr[j].x, o[l].x);
                     o[l].y = fmaf(ev.y, wr[j].y, o[l].y);
@@ -580,16 +601,26 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
             float4 v;
             v.x = fmaf(o[l].x, dsv.x, dbv.x); v.y = fmaf(o[l].y, dsv.y, dbv.y); v.z = fmaf(o[l].z, dsv.z, dbv.z); v.w = fmaf(o[l].w, dsv.w, dbv.w);
             v.x *= sigmoid_fast(v.x); v.y *= sigmoid_fast(v.y); v.z *= sigmoid_fast(v.z); v.w *= sigmoid_fast(v.w);
+            if constexpr (STRIDE == 2) {   // the last slot of a row has one output: its second one counts as zero
+                const float keep = 2 * cg + l < HO ? 1.f : 0.f;
+                v.x *= keep; v.y *= keep; v.z *= keep; v.w *= keep;
+            }
             o[l] = v;
             ps.x += v.x; ps.y += v.y; ps.z += v.z; ps.w += v.w;
             asm volatile("" : "+v"(o[l].x), "+v"(o[l].y), "+v"(o[l].z), "+v"(o[l].w), "+v"(ps.x), "+v"(ps.y), "+v"(ps.z), "+v"(ps.w));
-            if (step == HALF) {
+            if (step == NOUT) {
                 const int cb = chunk * XCH + q * 4;
                 const bool st_ok = tvalid && img_ok && cb < Cexp;
-                float* dst = y + (((size_t)(img_ok ? img0 : 0) * PX + trow * HW) * Cexp + (cb < Cexp ? cb : 0));
+                float* dst = y + (((size_t)(img_ok ? img0 : 0) * (HO * HO) + trow * HO) * Cexp + (cb < Cexp ? cb : 0));
                 if (st_ok) {
+                    if constexpr (STRIDE == 2) {   // 7 x 7 output: cache resident, plain stores
 #pragma unroll
-                    for (int l2 = 0; l2 < HALF; ++l2) x3_stream_store(dst + (size_t)ecol(l2) * Cexp, o[l2]);
+                        for (int l2 = 0; l2 < NOUT; ++l2)
+                            if (2 * cg + l2 < HO) *reinterpret_cast<float4*>(dst + (size_t)(2 * cg + l2) * Cexp) = o[l2];
+                    } else {
+#pragma unroll
+                        for (int l2 = 0; l2 < HALF; ++l2) x3_stream_store(dst + (size_t)ecol(l2) * Cexp, o[l2]);
+                    }
                 }
                 if (tvalid) *reinterpret_cast<float4*>(&red[task][q * 4]) = ps;
             }
@@ -600,7 +631,7 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
         if (!pooled || tid >= XCH) return;
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < HW; ++r) s += red[r][tid] + red[HW + r][tid];      // rows in order, left half + right half
+        for (int r = 0; r < HW; ++r) s += red[r][tid] + red[HW + r][tid];      // all task slots in a fixed order (stride 1: rows in order, left half + right half)
         const int cg = chunk * XCH + tid;
         if (cg < Cexp && img_ok) pooled[(size_t)img0 * Cexp + cg] = s;
     };

@@ -586,12 +586,22 @@ def expand_dwconv_supported(H, W, Cin, Cexp, ks, stride, pad) -> bool:
     """True when the fused expand + depthwise kernel covers this layer shape."""
     pt, pb, pl, pr = pad
     lib = N.load()
+    if _img_x3_s2(lib, H, W, Cin, Cexp, ks, stride, pad):
+        return True          # the stride-2 form of the whole-image split-product kernel (14 x 14 -> 7 x 7)
     if lib.icap_expand_dwconv_whole_image(H, W, Cin, Cexp, ks, stride) and (COMPUTE_DTYPE == "bf16" or (pt, pl) != (ks // 2, ks // 2)):
         return False         # the whole-image kernel of the 14x14 / 7x7 blocks: fp32 tensors, 'same' padding
     return lib.icap_expand_dwconv_chunks(conv_out_size(H, ks, stride, pt, pb), conv_out_size(W, ks, stride, pl, pr),
                                          Cin, Cexp, ks, stride) > 0
 
 
+def _img_x3_s2(lib, H, W, Cin, Cexp, ks, stride, pad) -> bool:
+    pt, pb, pl, pr = pad
+    return bool(COMPUTE_DTYPE == "f32x3" and IMG_X3 and IMG_X3_S2 and stride == 2
+                and conv_out_size(H, ks, stride, pt, pb) == 7 and conv_out_size(W, ks, stride, pl, pr) == 7
+                and lib.icap_expand_dwconv_img_x3_s2_supported(H, W, Cin, Cexp, ks, pt, pl))
+
+
+IMG_X3_S2 = True   # ... and the 14 x 14 -> 7 x 7 block on its stride-2 form (False: expand GEMM + depthwise kernel)
 IMG_X3 = True      # "f32x3" mode: the whole-image layer shapes on icap_expand_dwconv_img_x3_f32 (False: the fp32 whole-image kernel)
 
 
@@ -608,7 +618,8 @@ def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, k
     if w_exp.numel() != Cexp * Cin or tuple(w_dw.shape) != (ks * ks, Cexp):
         raise IcapError("expand_dwconv2d: weights must be [Cexp, Cin] and [ks*ks, Cexp]")
     lib = N.load()
-    nch = lib.icap_expand_dwconv_chunks(Ho, Wo, Cin, Cexp, ks, stride)
+    s2 = _img_x3_s2(lib, H, W, Cin, Cexp, ks, stride, pad)
+    nch = 1 if s2 else lib.icap_expand_dwconv_chunks(Ho, Wo, Cin, Cexp, ks, stride)
     if nch <= 0:
         raise IcapError(f"expand_dwconv2d: no fused kernel for Cin={Cin}, {ks}x{ks} stride {stride}")
     bf16 = COMPUTE_DTYPE == "bf16"
@@ -623,16 +634,17 @@ def expand_dwconv2d(x, w_exp, exp_scale, exp_bias, w_dw, dw_scale, dw_bias, *, k
     tail = (_ck(partial, "partial"), B, H, W, Cin, Cexp, ks, stride, pt, pl, Ho, Wo, _stream())
     if bf16:
         N.check(lib.icap_expand_dwconv_bf16_f32(*head, _ck(y, "y", ydt), int(out_bf16), *tail), "expand_dwconv2d")
-    elif (COMPUTE_DTYPE == "f32x3" and IMG_X3 and stride == 1 and (pt, pl) == (ks // 2, ks // 2)
-          and lib.icap_expand_dwconv_img_x3_we_bytes(H, W, Cin, Cexp, ks) > 0):
+    elif s2 or (COMPUTE_DTYPE == "f32x3" and IMG_X3 and stride == 1 and (pt, pl) == (ks // 2, ks // 2)
+                and lib.icap_expand_dwconv_img_x3_we_bytes(H, W, Cin, Cexp, ks) > 0):
         wp = cache.get(key) if cache is not None else None
         if wp is None:
             wp = torch.empty(lib.icap_expand_dwconv_img_x3_we_bytes(H, W, Cin, Cexp, ks) // 2, device=x.device, dtype=torch.bfloat16)
             N.check(lib.icap_expand_dwconv_img_x3_pack(_ck(w_exp, "w_exp"), wp.data_ptr(), H, W, Cin, Cexp, ks, _stream()), "expand_dwconv2d pack")
             if cache is not None:
                 cache[key] = wp
-        N.check(lib.icap_expand_dwconv_img_x3_f32(head[0], wp.data_ptr(), *head[2:], _ck(y, "y"), _ck(partial, "partial"), B, H, W, Cin,
-                                                  Cexp, ks, pt, pl, _stream()), "expand_dwconv2d")
+        run = lib.icap_expand_dwconv_img_x3_s2_f32 if s2 else lib.icap_expand_dwconv_img_x3_f32
+        N.check(run(head[0], wp.data_ptr(), *head[2:], _ck(y, "y"), _ck(partial, "partial"), B, H, W, Cin, Cexp, ks, pt, pl, _stream()),
+                "expand_dwconv2d")
     elif COMPUTE_DTYPE == "f32x3":
         N.check(lib.icap_expand_dwconv_f32x3_f32(*head, _ck(y, "y"), *tail), "expand_dwconv2d")
     else:

@@ -166,6 +166,17 @@ int icap_expand_dwconv_img_x3_f32(const float* x, const void* w_packed, const fl
                                   const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* pooled,
                                   int B, int H, int W, int Cin, int Cexp, int KS, int pad_t, int pad_l, void* stream);
 
+/* The same kernel for the block that halves the resolution at 14 x 14 (112 -> 672 channels, 5 x 5 depthwise, stride 2,
+ * TF-'same' padding: pad_t = pad_l = 1): x [B][14][14][Cin] -> y [B][7][7][Cexp], pooled [B][Cexp] or NULL; w_packed is
+ * what icap_expand_dwconv_img_x3_pack writes for (14, 14, Cin, Cexp, KS).  Replaces the pair icap_linear_f32x3_f32
+ * (expand + BN + swish) + icap_dwconv2d_f32: the expanded 14 x 14 tensor never reaches HBM.  icap_..._s2_supported
+ * returns 1 for the layer shapes that have a kernel.  Reference: MBConv block 11 of EfficientNet-B0
+ * (`_expand_conv` ... `_depthwise_conv` stride 2, transformer_word_level.py:13). */
+int icap_expand_dwconv_img_x3_s2_supported(int H, int W, int Cin, int Cexp, int KS, int pad_t, int pad_l);
+int icap_expand_dwconv_img_x3_s2_f32(const float* x, const void* w_packed, const float* exp_scale, const float* exp_bias,
+                                     const float* w_dw, const float* dw_scale, const float* dw_bias, float* y, float* pooled,
+                                     int B, int H, int W, int Cin, int Cexp, int KS, int pad_t, int pad_l, void* stream);
+
 /* The two fused kernels with bf16 products in their first (expand / stem) convolution - operands rounded to bf16 in
  * registers, fp32 accumulation on v_mfma_f32_32x32x16_bf16; the depthwise stage computes in fp32.  y is fp32
  * (y_bf16 = 0) or a bf16 tensor of the same shape (y_bf16 = 1, round to nearest even; the squeeze-excite partial sums

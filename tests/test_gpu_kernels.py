@@ -119,7 +119,9 @@ def test_dwconv_and_se(C, H, W, ks, s, pad):
                                                     # the whole-image kernel of the 14x14 / 7x7 stride-1 blocks (B = 3: a 7x7 group of four is ragged)
                                                     (80, 480, 14, 14, 3, 1, (1, 1, 1, 1)), (80, 480, 14, 14, 5, 1, (2, 2, 2, 2)),
                                                     (112, 672, 14, 14, 5, 1, (2, 2, 2, 2)), (112, 100, 14, 14, 3, 1, (1, 1, 1, 1)),
-                                                    (192, 1152, 7, 7, 5, 1, (2, 2, 2, 2)), (192, 1152, 7, 7, 3, 1, (1, 1, 1, 1))])
+                                                    (192, 1152, 7, 7, 5, 1, (2, 2, 2, 2)), (192, 1152, 7, 7, 3, 1, (1, 1, 1, 1)),
+                                                    # the block that halves 14 x 14: whole-image kernel, stride 2 (split products only)
+                                                    (112, 672, 14, 14, 5, 2, (1, 2, 1, 2)), (112, 100, 14, 14, 5, 2, (1, 2, 1, 2))])
 @pytest.mark.parametrize("mode", ["f32", "f32x3"])
 def test_fused_expand_dwconv(Cin, Cexp, H, W, ks, s, pad, mode):
     """1x1 expand + BN + swish + depthwise + BN + swish in one kernel == the two torch convolutions; sizes that do not
@@ -129,6 +131,12 @@ def test_fused_expand_dwconv(Cin, Cexp, H, W, ks, s, pad, mode):
     d = dev()
     ops.set_compute_dtype(mode)
     try:
+        if (H, s) == (14, 2) and mode != "f32x3":     # no fused kernel for this shape on the fp32 instruction: the caller
+            assert not ops.expand_dwconv_supported(H, W, Cin, Cexp, ks, s, pad)   # takes the two-kernel path, a direct call raises
+            with pytest.raises(ops.IcapError):
+                ops.expand_dwconv2d(torch.zeros(1, 14, 14, 112, device=d), torch.zeros(672, 112, device=d), None, None,
+                                    torch.zeros(25, 672, device=d), None, None, ks=5, stride=2, pad=(1, 2, 1, 2))
+            return
         _fused_expand_dwconv_case(ops, d, Cin, Cexp, H, W, ks, s, pad)
     finally:
         ops.set_compute_dtype("f32")
@@ -152,10 +160,7 @@ def _fused_expand_dwconv_case(ops, d, Cin, Cexp, H, W, ks, s, pad):
                                   want_partial=True)
     close(y.permute(0, 3, 1, 2), ref, what="expand+dwconv")
     close(part.sum(1) / (ref.shape[2] * ref.shape[3]), ref.mean((2, 3)), what="expand+dwconv partial pool")
-    assert not ops.expand_dwconv_supported(14, 14, 112, 672, 5, 2, (1, 2, 1, 2))
-    with pytest.raises(ops.IcapError):
-        ops.expand_dwconv2d(torch.zeros(1, 14, 14, 112, device=d), torch.zeros(672, 112, device=d), None, None,
-                            torch.zeros(25, 672, device=d), None, None, ks=5, stride=2, pad=(1, 2, 1, 2))
+    assert not ops.expand_dwconv_supported(14, 14, 112, 672, 3, 2, (0, 1, 0, 1))      # no kernel for this shape in any mode
 
 
 @pytest.mark.parametrize("H,W", [(56, 56), (45, 61)])

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * WPB) void thin_project_kernel(const ThinParams
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = 64 * i + lane;
-            xr[i] = src[e < room ? e : 0];                // rows past M: any valid address (their results are not stored)
+            xr[i] = __builtin_nontemporal_load(src + (e < room ? e : 0));   // read once: streaming; rows past M: any valid address (their results are not stored)
         }
         if (p.residual) {
 #pragma unroll

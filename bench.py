@@ -479,24 +479,24 @@ def decode_b1(torch, dev):
                                                  "opt-in (mode=\"persistent\"): needs the device to itself"}
     except Exception as e:      # noqa: BLE001 - a secondary figure must not take the line down
         out["bahdanau"]["persistent"] = {"error": f"{type(e).__name__}: {e}"}
-    # the two-layer LSTM's caption as one persistent launch (weights LDS-resident, two exchanges between workgroups per step)
-    try:
-        lm = next(m for kind, m in lstm_models if kind == "lstm")
-        same = bool(torch.equal(lm.sample_ids(f256, CAPTION_LEN, mode="persistent"), lm.sample_ids(f256, CAPTION_LEN)))
-        ms = timeit(lambda: lm.sample_ids(f256, CAPTION_LEN, mode="persistent", check=False))
-        us = ms * 1e3 / CAPTION_LEN
-        lw = lm._weights()
-        x1 = _ops.linear(f256, lw["ff_w"], bias=lw["ff_b"])
-        us_dec = timeit(lambda: _ops.greedy_lstm2_persist(lw, x1, CAPTION_LEN, check=False)) * 1e3 / CAPTION_LEN
-        gbs = DECODE_PARAMS["lstm"] * 4 / us / 1e3
-        out["lstm"]["persistent"] = {"us_per_step": us, "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
-                                     "decoder_call_only": {"us_per_step": us_dec, "hbm_frac": DECODE_PARAMS["lstm"] * 4 / us_dec / 1e3 / HBM_PEAK_GBS},
-                                     "ids_equal_default_path": same,
-                                     "note": "one launch per caption incl. its set-up (26 MB of weights into LDS, exchange buffers cleared), two "
-                                             "exchanges between the workgroups per step; timed without the read-back of the ids that detects a "
-                                             "launch which could not run (checked once before); opt-in (mode=\"persistent\"): needs the device to itself"}
-    except Exception as e:      # noqa: BLE001 - a secondary figure must not take the line down
-        out["lstm"]["persistent"] = {"error": f"{type(e).__name__}: {e}"}
+    # the two-layer LSTM's / GRU's caption as one persistent launch (weights LDS-resident, two exchanges between workgroups per step)
+    for kind, lm in lstm_models:
+        try:
+            same = bool(torch.equal(lm.sample_ids(f256, CAPTION_LEN, mode="persistent"), lm.sample_ids(f256, CAPTION_LEN)))
+            ms = timeit(lambda: lm.sample_ids(f256, CAPTION_LEN, mode="persistent", check=False))
+            us = ms * 1e3 / CAPTION_LEN
+            lw = lm._weights()
+            x1 = _ops.linear(f256, lw["ff_w"], bias=lw["ff_b"])
+            us_dec = timeit(lambda: _ops.greedy_rnn2_persist(lw, x1, CAPTION_LEN, check=False)) * 1e3 / CAPTION_LEN
+            gbs = DECODE_PARAMS[kind] * 4 / us / 1e3
+            out[kind]["persistent"] = {"us_per_step": us, "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                                       "decoder_call_only": {"us_per_step": us_dec, "hbm_frac": DECODE_PARAMS[kind] * 4 / us_dec / 1e3 / HBM_PEAK_GBS},
+                                       "ids_equal_default_path": same,
+                                       "note": "one launch per caption incl. its set-up (20-26 MB of weights into LDS, exchange buffers cleared), two "
+                                               "exchanges between the workgroups per step; timed without the read-back of the ids that detects a "
+                                               "launch which could not run (checked once before); opt-in (mode=\"persistent\"): needs the device to itself"}
+        except Exception as e:      # noqa: BLE001 - a secondary figure must not take the line down
+            out[kind]["persistent"] = {"error": f"{type(e).__name__}: {e}"}
     out["note"] = ("one caption in flight, fp32 weights, whole caption enqueued without host round trips; bytes = parameters touched per step x 4; "
                    "the char model's default (table) path is reported as captions/s and us per step-equivalent (caption time / 58): its weights are read once per caption; its bandwidth figures are those of the step-by-step forms (steps: one launch chain per step; persistent: one launch per caption)")
     return out

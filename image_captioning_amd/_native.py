@@ -134,9 +134,9 @@ SIGNATURES = {
     "icap_greedy_bah_persist_f32": (_i, [_p] * 10 + [_i] * 4 + [_p]),
     "icap_greedy_bah_fused_ws_floats": (_ll, [_i] * 3),
     "icap_greedy_bah_fused_f32": (_i, [_p] * 10 + [_i] * 4 + [_p]),
-    "icap_greedy_lstm2_persist_max_nb": (_i, [_i] * 2),
-    "icap_greedy_lstm2_persist_ws_bytes": (_ll, [_i] * 3),
-    "icap_greedy_lstm2_persist_f32": (_i, [_p] * 11 + [_i] * 4 + [_p]),
+    "icap_greedy_rnn2_persist_max_nb": (_i, [_i] * 3),
+    "icap_greedy_rnn2_persist_ws_bytes": (_ll, [_i] * 4),
+    "icap_greedy_rnn2_persist_f32": (_i, [_i] + [_p] * 13 + [_i] * 4 + [_p]),
     "icap_greedy_rnn2_fused_ws_floats": (_ll, [_i] * 4),
     "icap_greedy_rnn2_fused_f32": (_i, [_i] + [_p] * 13 + [_i] * 4 + [_p]),
     "icap_ce_loss_fwd_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _ll, _i, _p, _p, _p, _p]),

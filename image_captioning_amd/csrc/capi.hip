@@ -43,10 +43,10 @@ int linear_f32x3_splitk_f32(const float*, const unsigned short*, const float*, c
 int linear_thin_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, float*, long long, int, int,
                     hipStream_t);
 int greedy_bah_persist_max_nb(int, int);
-int greedy_lstm2_persist_max_nb(int, int);
-long long greedy_lstm2_persist_ws_bytes(int, int, int);
-int greedy_lstm2_persist_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                             long long*, float*, void*, int, int, int, int, hipStream_t);
+int greedy_rnn2_persist_max_nb(int, int, int);
+long long greedy_rnn2_persist_ws_bytes(int, int, int, int);
+int greedy_rnn2_persist_f32(int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                            const float*, const float*, long long*, float*, void*, int, int, int, int, hipStream_t);
 long long greedy_bah_persist_ws_bytes(int, int, int);
 int greedy_bah_persist_f32(const float*, const float*, const float*, const float*, const float*, const float*, const long long*, long long*,
                            float*, void*, int, int, int, int, hipStream_t);
@@ -676,13 +676,14 @@ int icap_linear_thin_f32(const float* x, const float* w, const float* scale, con
     return linear_thin_f32(x, w, scale, bias, residual, gate, hw, y, M, K, N, (hipStream_t)stream);
 }
 
-int icap_greedy_lstm2_persist_max_nb(int H, int V) { return greedy_lstm2_persist_max_nb(H, V); }
-long long icap_greedy_lstm2_persist_ws_bytes(int NB, int H, int V) { return greedy_lstm2_persist_ws_bytes(NB, H, V); }
-int icap_greedy_lstm2_persist_f32(const float* g_tab0, const float* g_first, const float* w_hh0, const float* w_ih1, const float* ih1_bias,
-                                  const float* w_hh1, const float* fc_w, const float* fc_b, long long* ids, float* logits_out, void* ws,
-                                  int NB, int H, int V, int steps, void* stream) {
-    return greedy_lstm2_persist_f32(g_tab0, g_first, w_hh0, w_ih1, ih1_bias, w_hh1, fc_w, fc_b, ids, logits_out, ws, NB, H, V, steps,
-                                    (hipStream_t)stream);
+int icap_greedy_rnn2_persist_max_nb(int is_lstm, int H, int V) { return greedy_rnn2_persist_max_nb(is_lstm, H, V); }
+long long icap_greedy_rnn2_persist_ws_bytes(int NB, int is_lstm, int H, int V) { return greedy_rnn2_persist_ws_bytes(NB, is_lstm, H, V); }
+int icap_greedy_rnn2_persist_f32(int is_lstm, const float* g_tab0, const float* g_first, const float* w_hh0, const float* hh0_bias,
+                                 const float* w_ih1, const float* ih1_bias, const float* w_hh1, const float* hh1_bias, const float* fc_w,
+                                 const float* fc_b, long long* ids, float* logits_out, void* ws, int NB, int H, int V, int steps,
+                                 void* stream) {
+    return greedy_rnn2_persist_f32(is_lstm, g_tab0, g_first, w_hh0, hh0_bias, w_ih1, ih1_bias, w_hh1, hh1_bias, fc_w, fc_b, ids, logits_out,
+                                   ws, NB, H, V, steps, (hipStream_t)stream);
 }
 
 int icap_greedy_bah_persist_max_nb(int H, int V) { return greedy_bah_persist_max_nb(H, V); }

@@ -1,5 +1,5 @@
-// Whole-caption persistent greedy decoder for the two-layer LSTM of DecoderRNN.sample (seq2seqbasic.py:68-91: nn.LSTM with
-// two layers of one width, Linear(H, V), arg-max, embedding of the arg-max as the next input): ONE launch runs every step of
+// Whole-caption persistent greedy decoder for the two-layer LSTM / GRU of DecoderRNN.sample (seq2seqbasic.py:68-91: nn.LSTM or
+// nn.GRU with two layers of one width, Linear(H, V), arg-max, embedding of the arg-max as the next input): ONE launch runs every step of
 // one or two captions, with the step's matrices - W_ih1, W_hh0, W_hh1 and the vocabulary projection, 26 MB for H = 512,
 // V = 6756 - resident in the LDS of a grid of workgroups, one per CU.
 //
@@ -18,6 +18,9 @@
 // step parity: a workgroup reaches the pass that overwrites a buffer only through an exchange that every other workgroup
 // feeds after its last read of that buffer.  Every spin is bounded; on a limit the workgroup raises `fail`, stops
 // publishing, the grid drains and workgroup 0 fills ids with -1.
+//
+// GRU: three gates (r, z, n) instead of four; the n gate keeps its two halves apart (n = tanh(in_n + r * (W_hn h + b_hn))), so the
+// recurrent biases b_hh travel separately (hh0_bias, hh1_bias) and count from step 0 on, and there is no cell state.
 #include <algorithm>
 #include <mutex>
 #include "decode.hpp"
@@ -30,7 +33,7 @@ constexpr unsigned PR_SPIN_LIMIT = 4000000u;
 constexpr int PR_LDS_BUDGET = 160 * 1024 - 1024;
 
 struct PrArgs {
-    const float *g_tab0, *g_first, *w_hh0, *w_ih1, *ih1_bias, *w_hh1, *fc_w, *fc_b;
+    const float *g_tab0, *g_first, *w_hh0, *hh0_bias, *w_ih1, *ih1_bias, *w_hh1, *hh1_bias, *fc_w, *fc_b;
     long long* ids;
     float* logits_out;
     unsigned long long *abuf, *hbuf, *lbuf;   // [2][NB][8H] (ih1 | hh0), [2][NB][4H] (hh1), [2][G][NB]
@@ -45,20 +48,21 @@ __device__ __forceinline__ void pr_publish(unsigned long long* slot, unsigned lo
 __device__ __forceinline__ float pr_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
 __device__ __forceinline__ float pr_tanh(float x) { return 2.f * pr_sigmoid(2.f * x) - 1.f; }
 
-// The four gate words of two neighbouring units from a published [4H] block (gate q of unit j at q * H + j): all eight are
+// The gate words of two neighbouring units from a published [NG * H] block (gate q of unit j at q * H + j): all eight are
 // requested before any is looked at, each is verified by its tag and the set is asked for again until it is complete.
 // Returns false when the spin limit was reached.
-__device__ __forceinline__ bool pr_read_gates(const unsigned long long* base, int H, unsigned tag, float (&out)[4][2]) {
-    unsigned long long w[4][2];
+template <int NG>
+__device__ __forceinline__ bool pr_read_gates(const unsigned long long* base, int H, unsigned tag, float (&out)[NG][2]) {
+    unsigned long long w[NG][2];
     unsigned spins = 0;
     for (;;) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NG; ++q)
 #pragma unroll
             for (int u = 0; u < 2; ++u) w[q][u] = __hip_atomic_load(base + q * H + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool all = true;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NG; ++q)
 #pragma unroll
             for (int u = 0; u < 2; ++u) all = all && (unsigned)(w[q][u] >> 32) == tag;
         if (all) break;
@@ -66,23 +70,47 @@ __device__ __forceinline__ bool pr_read_gates(const unsigned long long* base, in
         __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NG; ++q)
 #pragma unroll
         for (int u = 0; u < 2; ++u) out[q][u] = __uint_as_float((unsigned)w[q][u]);
     return true;
 }
 
-template <int NBT>
+// one cell update of two neighbouring units: in[q][u] the input side of gate q (biases included), hh[q][u] the recurrent side
+// (GRU: with b_hh), state at c (LSTM only) / h
+template <bool LSTM, int NG>
+__device__ __forceinline__ void pr_cell(const float (&in)[NG][2], const float (&hh)[NG][2], float* c, float* h) {
+    float hv[2], cv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if constexpr (LSTM) {
+            const float gi = in[0][u] + hh[0][u], gf = in[1][u] + hh[1][u], gg = in[2][u] + hh[2][u], go = in[3][u] + hh[3][u];
+            cv[u] = pr_sigmoid(gf) * c[u] + pr_sigmoid(gi) * pr_tanh(gg);
+            hv[u] = pr_sigmoid(go) * pr_tanh(cv[u]);
+        } else {
+            const float r = pr_sigmoid(in[0][u] + hh[0][u]), z = pr_sigmoid(in[1][u] + hh[1][u]);
+            const float n = pr_tanh(in[2][u] + r * hh[2][u]);
+            hv[u] = (1.f - z) * n + z * h[u];
+        }
+    }
+    if constexpr (LSTM) *reinterpret_cast<float2*>(c) = make_float2(cv[0], cv[1]);
+    *reinterpret_cast<float2*>(h) = make_float2(hv[0], hv[1]);
+}
+
+template <int NBT, bool LSTM>
 __global__ __launch_bounds__(PR_T) void rnn_persist_kernel(const PrArgs a) {
     extern __shared__ __align__(16) float lds[];
-    const int H = a.H, V = a.V, G = a.G, g = blockIdx.x, GH = 4 * H;
+    constexpr int NG = LSTM ? 4 : 3;
+    const int H = a.H, V = a.V, G = a.G, g = blockIdx.x, GH = NG * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* wa = lds;                                    // [r_a][H]   rows of [W_ih1; W_hh0]
     float* whh = wa + a.r_a * H;                        // [r_hh][H]  rows of W_hh1
     float* wfc = whh + a.r_hh * H;                      // [r_fc][H]
     float* fcb = wfc + a.r_fc * H;                      // [r_fc] (padded to 4 floats)
-    float* b1 = fcb + ((a.r_fc + 3) & ~3);              // [4H] b_ih1 + b_hh1
-    float* gfirst = b1 + GH;                            // [NB][4H]
+    float* b1 = fcb + ((a.r_fc + 3) & ~3);              // [GH] layer 1's input-side bias (LSTM: b_ih1 + b_hh1)
+    float* hb0 = b1 + GH;                               // [GH] b_hh0, [GH] b_hh1 (GRU; zeros for an LSTM)
+    float* hb1 = hb0 + GH;
+    float* gfirst = hb1 + GH;                           // [NB][GH]
     float* c0 = gfirst + NBT * GH;                      // [NB][H] each
     float* h0 = c0 + NBT * H;
     float* c1 = h0 + NBT * H;
@@ -105,10 +133,14 @@ __global__ __launch_bounds__(PR_T) void rnn_persist_kernel(const PrArgs a) {
     for (int i = tid * 4; i < nh * H; i += PR_T * 4) *reinterpret_cast<float4*>(whh + i) = *reinterpret_cast<const float4*>(a.w_hh1 + (size_t)rowh * H + i);
     for (int i = tid * 4; i < nf * H; i += PR_T * 4) *reinterpret_cast<float4*>(wfc + i) = *reinterpret_cast<const float4*>(a.fc_w + (size_t)rowf * H + i);
     for (int i = tid; i < nf; i += PR_T) fcb[i] = a.fc_b ? a.fc_b[rowf + i] : 0.f;
-    for (int i = tid; i < GH; i += PR_T) b1[i] = a.ih1_bias ? a.ih1_bias[i] : 0.f;
+    for (int i = tid; i < GH; i += PR_T) {
+        b1[i] = a.ih1_bias ? a.ih1_bias[i] : 0.f;
+        hb0[i] = a.hh0_bias ? a.hh0_bias[i] : 0.f;
+        hb1[i] = a.hh1_bias ? a.hh1_bias[i] : 0.f;
+    }
     for (int i = tid; i < NBT * GH; i += PR_T) gfirst[i] = a.g_first[i];
     // h = c = 0 in both layers: the first step's recurrent sides are W_hh . 0 = 0
-    for (int i = tid; i < NBT * H; i += PR_T) { c0[i] = 0.f; c1[i] = 0.f; }
+    for (int i = tid; i < NBT * H; i += PR_T) { c0[i] = 0.f; c1[i] = 0.f; h0[i] = 0.f; h1[i] = 0.f; }
     if (tid < NBT) toks[tid] = 0;
     __syncthreads();
 
@@ -151,31 +183,21 @@ __global__ __launch_bounds__(PR_T) void rnn_persist_kernel(const PrArgs a) {
         // ---- layer 0: h0(t) = cell(input row + hh0(t), c0), two units per thread, redone by every workgroup
         for (int e2 = tid; e2 < NBT * H2; e2 += PR_T) {
             const int b = e2 / H2, j = (e2 - b * H2) << 1;
-            float2 gt[4];
+            float in[NG][2], hh[NG][2];
             if (t == 0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gt[q] = *reinterpret_cast<const float2*>(gfirst + b * GH + q * H + j);
+                for (int q = 0; q < NG; ++q) { const float2 v = *reinterpret_cast<const float2*>(gfirst + b * GH + q * H + j); in[q][0] = v.x; in[q][1] = v.y; }
             } else {
                 const float* tr = a.g_tab0 + (size_t)toks[b] * GH + j;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gt[q] = *reinterpret_cast<const float2*>(tr + q * H);
+                for (int q = 0; q < NG; ++q) { const float2 v = *reinterpret_cast<const float2*>(tr + q * H); in[q][0] = v.x; in[q][1] = v.y; }
             }
-            float hh[4][2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hh[q][0] = hh[q][1] = 0.f;
-            if (t > 0 && !pr_read_gates(a.abuf + ((size_t)((t - 1) & 1) * NBT + b) * 2 * GH + GH + j, H, tag_prev, hh)) s_fail = 1;
-            float hv[2], cv[2];
+            for (int q = 0; q < NG; ++q) hh[q][0] = hh[q][1] = 0.f;
+            if (t > 0 && !pr_read_gates<NG>(a.abuf + ((size_t)((t - 1) & 1) * NBT + b) * 2 * GH + GH + j, H, tag_prev, hh)) s_fail = 1;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float gi = (u ? gt[0].y : gt[0].x) + hh[0][u];
-                const float gf = (u ? gt[1].y : gt[1].x) + hh[1][u];
-                const float gg = (u ? gt[2].y : gt[2].x) + hh[2][u];
-                const float go = (u ? gt[3].y : gt[3].x) + hh[3][u];
-                cv[u] = pr_sigmoid(gf) * c0[b * H + j + u] + pr_sigmoid(gi) * pr_tanh(gg);
-                hv[u] = pr_sigmoid(go) * pr_tanh(cv[u]);
-            }
-            *reinterpret_cast<float2*>(c0 + b * H + j) = make_float2(cv[0], cv[1]);
-            *reinterpret_cast<float2*>(h0 + b * H + j) = make_float2(hv[0], hv[1]);
+            for (int q = 0; q < NG; ++q) { hh[q][0] += hb0[q * H + j]; hh[q][1] += hb0[q * H + j + 1]; }
+            pr_cell<LSTM, NG>(in, hh, c0 + b * H + j, h0 + b * H + j);
         }
         __syncthreads();
         if (s_fail) { ok = false; break; }
@@ -204,23 +226,17 @@ __global__ __launch_bounds__(PR_T) void rnn_persist_kernel(const PrArgs a) {
         // ---- layer 1: h1(t) = cell(ih1(t) + b1 + hh1(t), c1), redone by every workgroup
         for (int e2 = tid; e2 < NBT * H2; e2 += PR_T) {
             const int b = e2 / H2, j = (e2 - b * H2) << 1;
-            float ih[4][2], hh[4][2];
+            float ih[NG][2], hh[NG][2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hh[q][0] = hh[q][1] = 0.f;
-            if (t > 0 && !pr_read_gates(a.hbuf + ((size_t)((t - 1) & 1) * NBT + b) * GH + j, H, tag_prev, hh)) s_fail = 1;
-            if (!pr_read_gates(a.abuf + ((size_t)(t & 1) * NBT + b) * 2 * GH + j, H, tag_now, ih)) s_fail = 1;
-            float hv[2], cv[2];
+            for (int q = 0; q < NG; ++q) hh[q][0] = hh[q][1] = 0.f;
+            if (t > 0 && !pr_read_gates<NG>(a.hbuf + ((size_t)((t - 1) & 1) * NBT + b) * GH + j, H, tag_prev, hh)) s_fail = 1;
+            if (!pr_read_gates<NG>(a.abuf + ((size_t)(t & 1) * NBT + b) * 2 * GH + j, H, tag_now, ih)) s_fail = 1;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float gi = ih[0][u] + b1[j + u] + hh[0][u];
-                const float gf = ih[1][u] + b1[H + j + u] + hh[1][u];
-                const float gg = ih[2][u] + b1[2 * H + j + u] + hh[2][u];
-                const float go = ih[3][u] + b1[3 * H + j + u] + hh[3][u];
-                cv[u] = pr_sigmoid(gf) * c1[b * H + j + u] + pr_sigmoid(gi) * pr_tanh(gg);
-                hv[u] = pr_sigmoid(go) * pr_tanh(cv[u]);
+            for (int q = 0; q < NG; ++q) {
+                ih[q][0] += b1[q * H + j]; ih[q][1] += b1[q * H + j + 1];
+                hh[q][0] += hb1[q * H + j]; hh[q][1] += hb1[q * H + j + 1];
             }
-            *reinterpret_cast<float2*>(c1 + b * H + j) = make_float2(cv[0], cv[1]);
-            *reinterpret_cast<float2*>(h1 + b * H + j) = make_float2(hv[0], hv[1]);
+            pr_cell<LSTM, NG>(ih, hh, c1 + b * H + j, h1 + b * H + j);
         }
         __syncthreads();
         if (s_fail) { ok = false; break; }
@@ -302,71 +318,75 @@ static int pr_cus() {
 // grid: the largest multiple of 64 workgroups that the CUs hold at one per CU, at most 256 (a wave polls the words of one caption)
 static int pr_grid() { return std::min(256, pr_cus() / 64 * 64); }
 
-static long long pr_lds_floats(int NB, int H, int r_a, int r_hh, int r_fc) {
-    return (long long)(r_a + r_hh + r_fc) * H + ((r_fc + 3) & ~3) + 4LL * H + (long long)NB * (4LL * H + 4LL * H) + PR_W * NB * 2 + 16;
+static long long pr_lds_floats(int NB, int NG, int H, int r_a, int r_hh, int r_fc) {
+    return (long long)(r_a + r_hh + r_fc) * H + ((r_fc + 3) & ~3) + 3LL * NG * H + (long long)NB * (NG * H + 4LL * H) + PR_W * NB * 2 + 16;
 }
 
 // captions per call the shape allows (0: not supported - use icap_greedy_rnn2_fused_f32 / icap_greedy_rnn_f32)
-int greedy_lstm2_persist_max_nb(int H, int V) {
-    const int G = pr_grid();
+int greedy_rnn2_persist_max_nb(int is_lstm, int H, int V) {
+    const int G = pr_grid(), NG = is_lstm ? 4 : 3;
     if (G < 64 || H <= 0 || V <= 0 || (H % 4) || V > 0x1fff0) return 0;
-    const int r_hh = (4 * H + G - 1) / G, r_a = 2 * r_hh, r_fc = (V + G - 1) / G;
+    const int r_hh = (NG * H + G - 1) / G, r_a = 2 * r_hh, r_fc = (V + G - 1) / G;
     for (int nb = std::min(2, PR_T / G); nb >= 1; --nb)
-        if (pr_lds_floats(nb, H, r_a, r_hh, r_fc) * 4 <= PR_LDS_BUDGET) return nb;
+        if (pr_lds_floats(nb, NG, H, r_a, r_hh, r_fc) * 4 <= PR_LDS_BUDGET) return nb;
     return 0;
 }
 
-long long greedy_lstm2_persist_ws_bytes(int NB, int H, int V) {
+long long greedy_rnn2_persist_ws_bytes(int NB, int is_lstm, int H, int V) {
     (void)V;
-    return 8LL * (2LL * NB * 8 * H + 2LL * NB * 4 * H + 2LL * 256 * NB) + 64;
+    const long long GH = (is_lstm ? 4LL : 3LL) * H;
+    return 8LL * (2LL * NB * 2 * GH + 2LL * NB * GH + 2LL * 256 * NB) + 64;
 }
 
-template <int NBT>
+template <int NBT, bool LSTM>
 static int pr_launch(PrArgs& a, size_t lds_bytes, hipStream_t st) {
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_persist_kernel<NBT>), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS_BUDGET);
+        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_persist_kernel<NBT, LSTM>), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS_BUDGET);
     });
-    if (attr_rc != hipSuccess) { set_error("greedy_lstm2_persist: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr_rc)); return ICAP_ERR_HIP_BASE + (int)attr_rc; }
-    hipLaunchKernelGGL(rnn_persist_kernel<NBT>, dim3(a.G), dim3(PR_T), lds_bytes, st, a);
-    return launch_status("greedy_lstm2_persist");
+    if (attr_rc != hipSuccess) { set_error("greedy_rnn2_persist: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr_rc)); return ICAP_ERR_HIP_BASE + (int)attr_rc; }
+    hipLaunchKernelGGL((rnn_persist_kernel<NBT, LSTM>), dim3(a.G), dim3(PR_T), lds_bytes, st, a);
+    return launch_status("greedy_rnn2_persist");
 }
 
-// Operands as icap_greedy_rnn2_fused_f32 takes them for an LSTM (is_lstm = 1, no separate recurrent biases).
-int greedy_lstm2_persist_f32(const float* g_tab0, const float* g_first, const float* w_hh0, const float* w_ih1, const float* ih1_bias,
-                             const float* w_hh1, const float* fc_w, const float* fc_b, long long* ids, float* logits_out, void* ws,
-                             int NB, int H, int V, int steps, hipStream_t st) {
+// Operands as icap_greedy_rnn2_fused_f32 takes them.
+int greedy_rnn2_persist_f32(int is_lstm, const float* g_tab0, const float* g_first, const float* w_hh0, const float* hh0_bias,
+                            const float* w_ih1, const float* ih1_bias, const float* w_hh1, const float* hh1_bias, const float* fc_w,
+                            const float* fc_b, long long* ids, float* logits_out, void* ws, int NB, int H, int V, int steps,
+                            hipStream_t st) {
     if (!g_tab0 || !g_first || !w_hh0 || !w_ih1 || !w_hh1 || !fc_w || !ids || !ws || NB <= 0 || steps <= 0) {
-        set_error("greedy_lstm2_persist: bad arguments");
+        set_error("greedy_rnn2_persist: bad arguments");
         return ICAP_ERR_ARG;
     }
-    const int max_nb = greedy_lstm2_persist_max_nb(H, V);
-    if (max_nb == 0) { set_error("greedy_lstm2_persist: H=%d V=%d does not fit the chip's LDS (or H is not a multiple of 4)", H, V); return ICAP_ERR_LIMIT; }
-    if (NB > max_nb) { set_error("greedy_lstm2_persist: NB=%d exceeds %d captions per call for this shape", NB, max_nb); return ICAP_ERR_LIMIT; }
-    if (steps > 10000) { set_error("greedy_lstm2_persist: at most 10000 steps"); return ICAP_ERR_LIMIT; }
+    const int max_nb = greedy_rnn2_persist_max_nb(is_lstm, H, V);
+    if (max_nb == 0) { set_error("greedy_rnn2_persist: H=%d V=%d does not fit the chip's LDS (or H is not a multiple of 4)", H, V); return ICAP_ERR_LIMIT; }
+    if (NB > max_nb) { set_error("greedy_rnn2_persist: NB=%d exceeds %d captions per call for this shape", NB, max_nb); return ICAP_ERR_LIMIT; }
+    if (steps > 10000) { set_error("greedy_rnn2_persist: at most 10000 steps"); return ICAP_ERR_LIMIT; }
     if (!aligned16(w_hh0) || !aligned16(w_ih1) || !aligned16(w_hh1) || !aligned16(fc_w) || !aligned16(g_tab0) ||
         (reinterpret_cast<uintptr_t>(g_first) & 7) || (reinterpret_cast<uintptr_t>(ws) & 7)) {
-        set_error("greedy_lstm2_persist: weights and table must be 16-byte aligned, g_first and ws 8-byte aligned");
+        set_error("greedy_rnn2_persist: weights and table must be 16-byte aligned, g_first and ws 8-byte aligned");
         return ICAP_ERR_ALIGN;
     }
+    const int NG = is_lstm ? 4 : 3;
     PrArgs a;
-    a.g_tab0 = g_tab0; a.g_first = g_first; a.w_hh0 = w_hh0; a.w_ih1 = w_ih1; a.ih1_bias = ih1_bias; a.w_hh1 = w_hh1;
-    a.fc_w = fc_w; a.fc_b = fc_b; a.ids = ids; a.logits_out = logits_out;
+    a.g_tab0 = g_tab0; a.g_first = g_first; a.w_hh0 = w_hh0; a.hh0_bias = hh0_bias; a.w_ih1 = w_ih1; a.ih1_bias = ih1_bias;
+    a.w_hh1 = w_hh1; a.hh1_bias = hh1_bias; a.fc_w = fc_w; a.fc_b = fc_b; a.ids = ids; a.logits_out = logits_out;
     a.H = H; a.V = V; a.NB = NB; a.steps = steps;
     a.G = pr_grid();
-    a.r_hh = (4 * H + a.G - 1) / a.G;
+    a.r_hh = (NG * H + a.G - 1) / a.G;
     a.r_a = 2 * a.r_hh;
     a.r_fc = (V + a.G - 1) / a.G;
     a.abuf = static_cast<unsigned long long*>(ws);
-    a.hbuf = a.abuf + 2LL * NB * 8 * H;
-    a.lbuf = a.hbuf + 2LL * NB * 4 * H;
+    a.hbuf = a.abuf + 2LL * NB * 2 * NG * H;
+    a.lbuf = a.hbuf + 2LL * NB * NG * H;
     a.fail = reinterpret_cast<int*>(a.lbuf + 2LL * 256 * NB);
     // tags start at 1 every launch: slots must not carry a previous launch's tags
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)greedy_lstm2_persist_ws_bytes(NB, H, V), st);
-    if (e != hipSuccess) { set_error("greedy_lstm2_persist: memset: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
-    const size_t lds_bytes = (size_t)pr_lds_floats(NB, H, a.r_a, a.r_hh, a.r_fc) * 4;
-    return NB == 1 ? pr_launch<1>(a, lds_bytes, st) : pr_launch<2>(a, lds_bytes, st);
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)greedy_rnn2_persist_ws_bytes(NB, is_lstm, H, V), st);
+    if (e != hipSuccess) { set_error("greedy_rnn2_persist: memset: %s", hipGetErrorString(e)); return ICAP_ERR_HIP_BASE + (int)e; }
+    const size_t lds_bytes = (size_t)pr_lds_floats(NB, NG, H, a.r_a, a.r_hh, a.r_fc) * 4;
+    if (is_lstm) return NB == 1 ? pr_launch<1, true>(a, lds_bytes, st) : pr_launch<2, true>(a, lds_bytes, st);
+    return NB == 1 ? pr_launch<1, false>(a, lds_bytes, st) : pr_launch<2, false>(a, lds_bytes, st);
 }
 
 }  // namespace icap

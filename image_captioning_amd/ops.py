@@ -1224,34 +1224,36 @@ def greedy_rnn2_fused(wd: dict, x0: torch.Tensor, steps: int, want_logits=False)
     return _graphed_caption(wd, ("rnn2f", NB, steps, bool(want_logits)), (x0,), run)
 
 
-def greedy_lstm2_persist_max_nb(H: int, V: int) -> int:
-    """Captions per call of the persistent whole-caption two-layer LSTM decoder for this shape; 0 = not supported."""
-    return N.load().icap_greedy_lstm2_persist_max_nb(H, V)
+def greedy_rnn2_persist_max_nb(is_lstm: bool, H: int, V: int) -> int:
+    """Captions per call of the persistent whole-caption two-layer LSTM / GRU decoder for this shape; 0 = not supported."""
+    return N.load().icap_greedy_rnn2_persist_max_nb(int(is_lstm), H, V)
 
 
-def greedy_lstm2_persist(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, check=True):
-    """greedy_rnn2_fused for an LSTM as ONE persistent launch with W_ih1, both W_hh and the vocabulary projection resident in
-    LDS (icap_greedy_lstm2_persist_f32).  The kernel needs all its workgroups resident at once (a plain launch on an otherwise
+def greedy_rnn2_persist(wd: dict, x0: torch.Tensor, steps: int, want_logits=False, check=True):
+    """greedy_rnn2_fused as ONE persistent launch with W_ih1, both W_hh and the vocabulary projection resident in LDS
+    (icap_greedy_rnn2_persist_f32).  The kernel needs all its workgroups resident at once (a plain launch on an otherwise
     idle device); a launch that could not make progress gives up after a bounded spin and leaves -1 in every id.  check=True
     (the default) reads the ids back - one host synchronisation - and raises IcapError for such a launch."""
     lib = N.load()
     NB, I = x0.shape
     H = wd["w_hh"][0].shape[1]
     V = wd["fc_w"].shape[0]
-    if not wd["is_lstm"] or len(wd["w_ih"]) != 2 or I != H or wd["w_ih"][1].shape[1] != H:
-        raise IcapError("greedy_lstm2_persist: needs a two-layer LSTM of one width")
+    if len(wd["w_ih"]) != 2 or I != H or wd["w_ih"][1].shape[1] != H:
+        raise IcapError("greedy_rnn2_persist: needs two layers of one width")
     t = _rnn2_fused_tables(wd)
+    lstm = int(wd["is_lstm"])
     dev = x0.device
     g_first = linear(x0, wd["w_ih"][0], bias=t["in_bias0"])
     ids = torch.empty((NB, steps), device=dev, dtype=torch.int64)
     logits = torch.empty((steps, NB, V), device=dev, dtype=torch.float32) if want_logits else None
-    ws = torch.empty((lib.icap_greedy_lstm2_persist_ws_bytes(NB, H, V) + 7) // 8, device=dev, dtype=torch.int64)
-    N.check(lib.icap_greedy_lstm2_persist_f32(_ck(t["g_tab0"], "g_tab0"), _ck(g_first, "g_first"), _ck(wd["w_hh"][0], "w_hh0"),
-                                              _ck(wd["w_ih"][1], "w_ih1"), _ck(t["ih1_bias"], "ih1_bias"), _ck(wd["w_hh"][1], "w_hh1"),
-                                              _ck(wd["fc_w"], "fc_w"), _ck(wd["fc_b"], "fc_b"), _ck(ids, "ids", torch.int64),
-                                              _ck(logits, "logits"), ws.data_ptr(), NB, H, V, steps, _stream()), "greedy_lstm2_persist")
+    ws = torch.empty((lib.icap_greedy_rnn2_persist_ws_bytes(NB, lstm, H, V) + 7) // 8, device=dev, dtype=torch.int64)
+    N.check(lib.icap_greedy_rnn2_persist_f32(lstm, _ck(t["g_tab0"], "g_tab0"), _ck(g_first, "g_first"), _ck(wd["w_hh"][0], "w_hh0"),
+                                             _ck(t["hh0_bias"], "hh0_bias"), _ck(wd["w_ih"][1], "w_ih1"), _ck(t["ih1_bias"], "ih1_bias"),
+                                             _ck(wd["w_hh"][1], "w_hh1"), _ck(t["hh1_bias"], "hh1_bias"), _ck(wd["fc_w"], "fc_w"),
+                                             _ck(wd["fc_b"], "fc_b"), _ck(ids, "ids", torch.int64), _ck(logits, "logits"), ws.data_ptr(),
+                                             NB, H, V, steps, _stream()), "greedy_rnn2_persist")
     if check and bool((ids < 0).any().item()):
-        raise IcapError("greedy_lstm2_persist: the persistent launch could not make progress (its workgroups were not all resident); "
+        raise IcapError("greedy_rnn2_persist: the persistent launch could not make progress (its workgroups were not all resident); "
                         "use greedy_rnn")
     return ids, logits
 

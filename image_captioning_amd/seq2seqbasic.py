@@ -146,20 +146,20 @@ class DecoderRNN(nn.Module):
     def sample_ids(self, features, max_len=20, want_logits=False, mode="auto", check=True):
         """Greedy token ids for a batch of feature rows, [B, max_len] on the device (no host sync).
         Every row is decoded independently, exactly as the reference decodes one image at a time.
-        mode="persistent" (two-layer LSTM only): whole captions as single launches with LDS-resident weights, one or two
-        captions per launch (ops.greedy_lstm2_persist; opt-in: it needs the device to itself and synchronises with the host
-        once per launch unless check=False)."""
+        mode="persistent" (two layers): whole captions as single launches with LDS-resident weights, one or two captions per
+        launch (ops.greedy_rnn2_persist; opt-in: it needs the device to itself and synchronises with the host once per launch
+        unless check=False)."""
         require_eval(self, "DecoderRNN")
         wd = self._weights()
         feats = features.float().contiguous().view(-1, features.shape[-1])
         x0 = ops.linear(feats, wd["ff_w"], bias=wd["ff_b"])
         ids, logits = [], []
         if mode == "persistent":
-            nb = ops.greedy_lstm2_persist_max_nb(wd["w_hh"][0].shape[1], wd["fc_w"].shape[0]) if wd["is_lstm"] and len(wd["w_ih"]) == 2 else 0
+            nb = ops.greedy_rnn2_persist_max_nb(wd["is_lstm"], wd["w_hh"][0].shape[1], wd["fc_w"].shape[0]) if len(wd["w_ih"]) == 2 else 0
             if nb <= 0:
-                raise ops.IcapError("DecoderRNN.sample_ids: the persistent form needs a two-layer LSTM whose weights fit the chip's LDS")
+                raise ops.IcapError("DecoderRNN.sample_ids: the persistent form needs two layers whose weights fit the chip's LDS")
             step = nb
-            run = lambda x: ops.greedy_lstm2_persist(wd, x, max_len, want_logits, check=check)
+            run = lambda x: ops.greedy_rnn2_persist(wd, x, max_len, want_logits, check=check)
         elif mode == "auto":
             step = MAX_LOCKSTEP
             run = lambda x: ops.greedy_rnn(wd, x, max_len, want_logits)

@@ -526,18 +526,19 @@ int icap_greedy_bah_w16_f32(const icap_bah_weights* w, const float* context, int
  *   icap_greedy_rnn_f32: three).  g_tab0 [V][G*H] = in_table . W_ih0^T + b_ih0 (LSTM: + b_hh0); g_first [NB][G*H] the same
  *   for the image feature, step 0's input; hh0_bias / hh1_bias = b_hh of the layer for a GRU (its n gate keeps the two
  *   halves apart), NULL for an LSTM; ih1_bias = b_ih1 (LSTM: + b_hh1). */
-/* icap_greedy_lstm2_persist_f32: the two-layer LSTM of icap_greedy_rnn2_fused_f32 (is_lstm = 1, same operands) as ONE
- * persistent launch for a whole caption: W_ih1, W_hh0, W_hh1 and the vocabulary projection stay in the LDS of a grid of
- * workgroups (one per CU), a step is two exchanges through 64-bit {value, tag} words in `ws`
- * (icap_greedy_lstm2_persist_ws_bytes bytes, 8-byte aligned; cleared by the call).  NB <= icap_greedy_lstm2_persist_max_nb(H, V)
- * (0: the shape does not fit; at most 2).  All workgroups must be resident at once: a launch that cannot make progress gives
- * up after a bounded spin and writes -1 into every id.  ids [NB][steps]; logits_out [steps][NB][V] or NULL.  Same reference
- * lines as icap_greedy_rnn_f32 (seq2seqbasic.py:68-91). */
-int icap_greedy_lstm2_persist_max_nb(int H, int V);
-long long icap_greedy_lstm2_persist_ws_bytes(int NB, int H, int V);
-int icap_greedy_lstm2_persist_f32(const float* g_tab0, const float* g_first, const float* w_hh0, const float* w_ih1,
-                                  const float* ih1_bias, const float* w_hh1, const float* fc_w, const float* fc_b, long long* ids,
-                                  float* logits_out, void* ws, int NB, int H, int V, int steps, void* stream);
+/* icap_greedy_rnn2_persist_f32: the two-layer LSTM / GRU of icap_greedy_rnn2_fused_f32 (same operands) as ONE persistent launch
+ * for a whole caption: W_ih1, W_hh0, W_hh1 and the vocabulary projection stay in the LDS of a grid of workgroups (one per
+ * CU), a step is two exchanges through 64-bit {value, tag} words in `ws` (icap_greedy_rnn2_persist_ws_bytes bytes, 8-byte
+ * aligned; cleared by the call).  NB <= icap_greedy_rnn2_persist_max_nb(is_lstm, H, V) (0: the shape does not fit; at most 2).
+ * All workgroups must be resident at once: a launch that cannot make progress gives up after a bounded spin and writes -1
+ * into every id.  ids [NB][steps]; logits_out [steps][NB][V] or NULL.  Same reference lines as icap_greedy_rnn_f32
+ * (seq2seqbasic.py:68-91). */
+int icap_greedy_rnn2_persist_max_nb(int is_lstm, int H, int V);
+long long icap_greedy_rnn2_persist_ws_bytes(int NB, int is_lstm, int H, int V);
+int icap_greedy_rnn2_persist_f32(int is_lstm, const float* g_tab0, const float* g_first, const float* w_hh0,
+                                 const float* hh0_bias, const float* w_ih1, const float* ih1_bias, const float* w_hh1,
+                                 const float* hh1_bias, const float* fc_w, const float* fc_b, long long* ids,
+                                 float* logits_out, void* ws, int NB, int H, int V, int steps, void* stream);
 long long icap_greedy_bah_fused_ws_floats(int NB, int H, int V);
 int icap_greedy_bah_fused_f32(const float* g_tab, const float* g_ctx, const float* w_hh, const float* fc_w,
                               const float* fc_scale, const float* fc_bias, const long long* start_ids, long long* ids,

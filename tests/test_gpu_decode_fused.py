@@ -139,16 +139,17 @@ def test_fused_entry_points_with_wider_groups(nb):
     H.assert_ids_match(ids.cpu().numpy(), ids_ref.cpu().numpy(), np.where(gap < 1e-3, 0.0, 1.0), f"bahdanau fused nb={nb}")
 
 
-def test_lstm2_persistent_caption():
-    """The two-layer LSTM's whole caption as one persistent launch (icap_greedy_lstm2_persist_f32): golden ids at the small
-    widths, and at the reference's widths ids / logits against the launch-per-cell driver, one and two captions per launch
-    (five captions: 2 + 2 + 1), twice in a row (the exchange buffers are cleared per call)."""
+@pytest.mark.parametrize("kind", ["lstm", "gru"])
+def test_rnn2_persistent_caption(kind):
+    """The two-layer LSTM's / GRU's whole caption as one persistent launch (icap_greedy_rnn2_persist_f32): golden ids at the
+    small widths, and at the reference's widths ids / logits against the launch-per-cell driver, one and two captions per
+    launch (five captions: 2 + 2 + 1), twice in a row (the exchange buffers are cleared per call)."""
     from image_captioning_amd import ops
-    g = H.load("seq2seq_lstm_small")
-    m = H.rnn_decoder("lstm", g["dims"]).to(dev())
+    g = H.load(f"seq2seq_{kind}_small")
+    m = H.rnn_decoder(kind, g["dims"]).to(dev())
     feats = H.features(8, int(g["dims"][0]), 101).to(dev())
-    _compare(lambda f: m.sample_ids(f, 20, want_logits=True, mode="persistent"), feats, g, "lstm persistent")
-    mb = H.rnn_decoder("lstm", (256, 512, 6756, 2)).to(dev())
+    _compare(lambda f: m.sample_ids(f, 20, want_logits=True, mode="persistent"), feats, g, f"{kind} persistent")
+    mb = H.rnn_decoder(kind, (256, 512, 6756, 2)).to(dev())
     feats = H.features(5, 256, 303).to(dev())
     ops.set_decode_fused(False)
     try:
@@ -159,14 +160,14 @@ def test_lstm2_persistent_caption():
     gap = (top2[..., 0] - top2[..., 1]).t().cpu().numpy()
     for rep in range(2):
         ids, lg = mb.sample_ids(feats, 12, want_logits=True, mode="persistent")
-        _close(lg, lg_ref, f"lstm persistent 512 (call {rep})")
-        H.assert_ids_match(ids.cpu().numpy(), ids_ref.cpu().numpy(), np.where(gap < 1e-3, 0.0, 1.0), f"lstm persistent 512 (call {rep})")
-    assert ops.greedy_lstm2_persist_max_nb(512, 6756) == 2
+        _close(lg, lg_ref, f"{kind} persistent 512 (call {rep})")
+        H.assert_ids_match(ids.cpu().numpy(), ids_ref.cpu().numpy(), np.where(gap < 1e-3, 0.0, 1.0), f"{kind} persistent 512 (call {rep})")
+    assert ops.greedy_rnn2_persist_max_nb(kind == "lstm", 512, 6756) == 2
     wd = mb._weights()
     with pytest.raises(ops.IcapError):
-        ops.greedy_lstm2_persist(wd, torch.zeros(3, 512, device=dev()), 4)
-    with pytest.raises(ops.IcapError):      # a GRU has no persistent form
-        H.rnn_decoder("gru", (256, 512, 6756, 2)).to(dev()).sample_ids(feats, 4, mode="persistent")
+        ops.greedy_rnn2_persist(wd, torch.zeros(3, 512, device=dev()), 4)
+    with pytest.raises(ops.IcapError):      # one layer has no persistent form
+        H.rnn_decoder(kind, (32, 64, 97, 1)).to(dev()).sample_ids(H.features(1, 32, 7).to(dev()), 4, mode="persistent")
 
 
 def test_bahdanau_persistent_caption():

@@ -51,8 +51,12 @@ constexpr int xd_waves() {
 // 3: fp32-accurate on the bf16 instruction - both operands as exact three-way bf16 splits (hi, mid, lo), the six products
 // hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi per K block (the dropped three are <= 2^-24 of the product): for CIN = 24,
 // 12 bf16 MFMAs of 32 cycles instead of 12 fp32 MFMAs of 64.
-template <int CIN, int KS, int S, int TH, int TW, int SW, bool STEM = false, int PROD = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS, S, TH, TW, STEM && PROD == 1>()))) void expand_dw_kernel(
+// ALLC > 0: the layer has at most ALLC channel chunks and the workgroup keeps EVERY chunk's parameters on chip from the start
+// (packed B planes and biases in registers, depthwise rows in LDS): no load inside the chunk loop, so no wait that would also
+// wait for the previous chunk's output stores (vmcnt counts loads and stores in one order).  Only where registers and LDS
+// allow it without losing a workgroup per CU: the 16-channel layer (three chunks).
+template <int CIN, int KS, int S, int TH, int TW, int SW, bool STEM = false, int PROD = 0, int ALLC = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALLC ? 4 : xd_waves<KS, S, TH, TW, STEM && PROD == 1>()))) void expand_dw_kernel(
     const float* __restrict__ x, const float* __restrict__ we, const float* __restrict__ es, const float* __restrict__ eb,
     const float* __restrict__ wd, const float* __restrict__ dsc, const float* __restrict__ dbi, float* __restrict__ y,
     float* __restrict__ partial, int H, int W, int Cexp, int pad_t, int pad_l, int Ho, int Wo, int tiles_w, int cpg,
@@ -60,6 +64,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     const int out16 = flags & 1;            // flags: bit 0 = bf16 output tensor, bit 1 (stem) = x is the planar [B][3][img_h][img_w] image
     static_assert(!STEM || CIN == 40, "the stem patch is 36 values padded to 40");
     static_assert(PROD == 0 || PROD == 1 || (PROD == 3 && !STEM), "split products: expanding blocks only");
+    static_assert(ALLC == 0 || (PROD == 3 && ALLC <= 3), "all-chunk parameters: split products, at most three chunks");
     constexpr bool BF16 = PROD != 0;       // operands go through packed bf16 registers
     constexpr int NPL = PROD == 3 ? 3 : 1;  // bf16 planes per operand
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS, P = IH * IW;
@@ -78,7 +83,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     // MFMA phase
     constexpr int WROWS = KS * KS + 1;
     static_assert(WROWS * 8 <= 256, "one float4 of the chunk's depthwise parameters per thread");
-    __shared__ float4 Wl[2][WROWS][8];
+    // ALLC: one block per chunk, without the bias row (kept in the pad columns of E)
+    __shared__ float4 Wl[ALLC ? ALLC : 2][ALLC ? KS * KS : WROWS][8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -221,7 +227,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
     };
     uint4 a16[BF16 ? NRB : 1][NPL][NCH], b16[NPL][NCH];
     const int ch_begin = blockIdx.z * cpg;
-    {
+    uint4 b16all[ALLC > 1 ? ALLC - 1 : 1][NPL][NCH];     // chunks 1 .. ALLC - 1 (chunk 0's planes go straight into b16)
+    float biall[ALLC > 1 ? ALLC - 1 : 1];
+    if constexpr (ALLC > 0) {
+        // every chunk's parameters, once (the host launches this form only for <= ALLC chunks in one z slice)
+#pragma unroll
+        for (int c = 0; c < ALLC; ++c) {
+            const int chc = c < ch_end ? c : ch_end - 1;
+            float braw[KH2], s_;
+            load_expand_params(chc, braw, s_, c == 0 ? bi : biall[c ? c - 1 : 0]);
+            float4 wv, ws4;
+            load_dw_params(chc, wv, ws4);
+            fold_b(bf, braw, s_);
+            if (c == 0) pack_planes(bf, b16);
+            else pack_planes(bf, b16all[c ? c - 1 : 0]);
+            if (wrow < KS * KS) Wl[c][wrow][q] = fold_dw(wv, ws4);
+            // the bias row goes into the four pad floats of E's rows c * 8 + q (columns 32..35: nothing else writes them)
+            else if (wrow == KS * KS) *reinterpret_cast<float4*>(&E[(c * 8 + q) * XD_LDE + XD_CC]) = wv;
+        }
+    } else {
         float braw[KH2], s_;
         load_expand_params(ch_begin, braw, s_, bi);
         float4 wv, ws4;
@@ -251,9 +275,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
         const int c0 = ch * XD_CC;
         const int chn = ch + 1 < ch_end ? ch + 1 : ch;
         float bfn[KH2], scn, bin;
-        load_expand_params(chn, bfn, scn, bin);
         float4 wln, wsn;
-        load_dw_params(chn, wln, wsn);
+        if constexpr (ALLC == 0) {
+            load_expand_params(chn, bfn, scn, bin);
+            load_dw_params(chn, wln, wsn);
+        }
         // ---- expand: E = swish(bn(A W^T)) for 32 channels ----
         {
 #pragma unroll
@@ -315,20 +341,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xd_waves<KS
                 }
             }
         }
-        if (wrow < WROWS) Wl[(ch + 1) & 1][wrow][q] = fold_dw(wln, wsn);
-        // the next chunk's B fragments take their place now, not at the end of the chunk: a wait for their loads there
-        // would also wait for the depthwise phase's stores, which have only just been issued
-        fold_b(bf, bfn, scn);
-        if constexpr (BF16) pack_planes(bf, b16);
-        bi = bin;
+        if constexpr (ALLC > 0) {
+            // the next chunk's planes and bias out of the registers that hold every chunk's (wave-uniform selection)
+#pragma unroll
+            for (int c = 1; c < ALLC; ++c)
+                if (chn == c) {
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) b16[p][k] = b16all[c - 1][p][k];
+                    bi = biall[c - 1];
+                }
+        } else {
+            if (wrow < WROWS) Wl[(ch + 1) & 1][wrow][q] = fold_dw(wln, wsn);
+            // the next chunk's B fragments take their place now, not at the end of the chunk: a wait for their loads there
+            // would also wait for the depthwise phase's stores, which have only just been issued
+            fold_b(bf, bfn, scn);
+            if constexpr (BF16) pack_planes(bf, b16);
+            bi = bin;
+        }
         __syncthreads();
 
         // ---- depthwise over E ----
         const int c = c0 + q * 4;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < Cexp) {
-            const float4 (*wl)[8] = Wl[ch & 1];
-            const float4 bi4 = wl[KS * KS][q];
+            const float4 (*wl)[8] = Wl[ALLC ? ch : ch & 1];
+            float4 bi4;
+            if constexpr (ALLC > 0) {
+                bi4 = *reinterpret_cast<const float4*>(&E[(ch * 8 + q) * XD_LDE + XD_CC]);
+            } else {
+                bi4 = wl[KS * KS][q];
+            }
             for (int st = sidx; st < NSTRIP; st += 32) {
                 const int ro = st / SPR;
                 const int so = (st - ro * SPR) * SW;
@@ -474,20 +518,23 @@ int expand_dwconv_f32(const float* x, const float* we, const float* es, const fl
     const int cpg = (nchunks + zg - 1) / zg;
     zg = (nchunks + cpg - 1) / cpg;
     const dim3 grid(ntiles, B, zg), block(256);
-#define ICAP_XD(CIN_, KS_, S_, TH_, TW_, SW_)                                                                                     \
+#define ICAP_XD(CIN_, KS_, S_, TH_, TW_, SW_, ALLC_)                                                                                   \
     do {                                                                                                                          \
-        if (x3) hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_, false, 3>), grid, block, 0, st, x, we, es,     \
+        if (x3 && (ALLC_) > 0 && zg == 1 && nchunks <= (ALLC_))                                                                    \
+            hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_, false, 3, ALLC_>), grid, block, 0, st, x, we, es,   \
+                               eb, wd, ds, db, y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0, 0);         \
+        else if (x3) hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_, false, 3>), grid, block, 0, st, x, we, es, \
                                    eb, wd, ds, db, y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0, 0);     \
         else if (bf16) hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_, false, 1>), grid, block, 0, st, x, we, es, \
                                      eb, wd, ds, db, y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0, out16); \
         else hipLaunchKernelGGL((expand_dw_kernel<CIN_, KS_, S_, TH_, TW_, SW_>), grid, block, 0, st, x, we, es, eb, wd, ds, db,  \
                                 y, partial, H, W, Cexp, pad_t, pad_l, Ho, Wo, tiles_w, cpg, 0, 0, 0, 0, out16);                   \
     } while (0)
-    if (Cin == 16) ICAP_XD(16, 3, 2, 7, 8, 2);
-    else if (Cin == 24 && KS == 3) ICAP_XD(24, 3, 1, 14, 14, 7);
-    else if (Cin == 24) ICAP_XD(24, 5, 2, 7, 7, 2);
-    else if (Cin == 40 && KS == 5) ICAP_XD(40, 5, 1, 14, 14, 7);
-    else ICAP_XD(40, 3, 2, 7, 7, 2);
+    if (Cin == 16) ICAP_XD(16, 3, 2, 7, 8, 2, 3);
+    else if (Cin == 24 && KS == 3) ICAP_XD(24, 3, 1, 14, 14, 7, 0);
+    else if (Cin == 24) ICAP_XD(24, 5, 2, 7, 7, 2, 0);
+    else if (Cin == 40 && KS == 5) ICAP_XD(40, 5, 1, 14, 14, 7, 0);
+    else ICAP_XD(40, 3, 2, 7, 7, 2, 0);
 #undef ICAP_XD
     return launch_status("expand_dwconv");
 }

@@ -142,8 +142,20 @@ def test_fused_expand_dwconv(Cin, Cexp, H, W, ks, s, pad, mode):
         ops.set_compute_dtype("f32")
 
 
-def _fused_expand_dwconv_case(ops, d, Cin, Cexp, H, W, ks, s, pad):
-    B = 3
+@pytest.mark.parametrize("Cexp", [96, 80])
+def test_fused_expand_dwconv_all_chunk_parameters(Cexp):
+    """The 16-channel layer with at most three channel chunks and enough workgroups for one z slice (tiles x images >= 4096)
+    runs the kernel form that keeps every chunk's parameters on chip (bias rows in the pad columns of the LDS tile): a batch
+    of 700 images of 30 x 30 (ragged tiles on two borders), a full last chunk and a half-empty one."""
+    from image_captioning_amd import ops
+    ops.set_compute_dtype("f32x3")
+    try:
+        _fused_expand_dwconv_case(ops, dev(), 16, Cexp, 30, 30, 3, 2, (0, 1, 0, 1), B=700)
+    finally:
+        ops.set_compute_dtype("f32")
+
+
+def _fused_expand_dwconv_case(ops, d, Cin, Cexp, H, W, ks, s, pad, B=3):
     x = rnd(B, Cin, H, W, seed=1)
     we = rnd(Cexp, Cin, 1, 1, seed=2, scale=Cin ** -0.5)
     es, eb = torch.rand(Cexp, generator=torch.Generator().manual_seed(3)) + 0.5, rnd(Cexp, seed=4, scale=0.3)

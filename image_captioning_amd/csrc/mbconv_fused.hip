@@ -170,20 +170,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALLC ? 4 : 
     // thread t < WROWS*8 owns float4 (row t/8, quad t%8) of the chunk's depthwise parameter block: a weight row (to be
     // multiplied by the folded-BN scale, fold_dw) or the bias row
     const int wrow = tid >> 3;
+    // Every thread issues the same two loads from valid addresses, whatever its row means; what the values mean (weight row
+    // x scale, bias row, nothing) is sorted out where they are used (fold_dw).  Loads under divergent branches would make the
+    // compiler wait for them at the joins - right where they were issued, in every chunk.
+    const bool dw_wt = wrow < KS * KS;                 // this thread's row is a filter tap (else: the bias row, or none)
+    const float* dw_vsrc = dw_wt ? wd + (size_t)wrow * Cexp : (dbi ? dbi : wd);
+    const float* dw_ssrc = dsc ? dsc : wd;
     auto load_dw_params = [&](int ch, float4& v, float4& s4) {
         const int c = ch * XD_CC + q * 4;
-        v = make_float4(0.f, 0.f, 0.f, 0.f);
-        s4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (wrow < WROWS && c < Cexp) {
-            if (wrow < KS * KS) {
-                v = *reinterpret_cast<const float4*>(wd + (size_t)wrow * Cexp + c);
-                if (dsc) s4 = *reinterpret_cast<const float4*>(dsc + c);
-            } else if (dbi) {
-                v = *reinterpret_cast<const float4*>(dbi + c);
-            }
-        }
+        const int cc = c < Cexp ? c : 0;
+        v = *reinterpret_cast<const float4*>(dw_vsrc + cc);
+        s4 = *reinterpret_cast<const float4*>(dw_ssrc + cc);
     };
-    auto fold_dw = [&](const float4& v, const float4& s4) { return make_float4(v.x * s4.x, v.y * s4.y, v.z * s4.z, v.w * s4.w); };
+    auto fold_dw = [&](int ch, const float4& v, const float4& s4) {
+        const bool live = wrow < WROWS && ch * XD_CC + q * 4 < Cexp && (dw_wt || dbi);
+        const bool scaled = dw_wt && dsc;
+        const float4 s = scaled ? s4 : make_float4(1.f, 1.f, 1.f, 1.f);
+        return live ? make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
     // bf16 products (BF16): a lane's KH2 values become ceil(KH2 / 8) packed chunks of 8 (zero padded); chunk c of both
     // lane halves is one K = 16 block of v_mfma_f32_32x32x16_bf16 - A and B use the same assignment, so any works
     constexpr int NCH = (KH2 + 7) / 8;
@@ -241,9 +245,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALLC ? 4 : 
             fold_b(bf, braw, s_);
             if (c == 0) pack_planes(bf, b16);
             else pack_planes(bf, b16all[c ? c - 1 : 0]);
-            if (wrow < KS * KS) Wl[c][wrow][q] = fold_dw(wv, ws4);
+            if (wrow < KS * KS) Wl[c][wrow][q] = fold_dw(chc, wv, ws4);
             // the bias row goes into the four pad floats of E's rows c * 8 + q (columns 32..35: nothing else writes them)
-            else if (wrow == KS * KS) *reinterpret_cast<float4*>(&E[(c * 8 + q) * XD_LDE + XD_CC]) = wv;
+            else if (wrow == KS * KS) *reinterpret_cast<float4*>(&E[(c * 8 + q) * XD_LDE + XD_CC]) = fold_dw(chc, wv, ws4);
         }
     } else {
         float braw[KH2], s_;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALLC ? 4 : 
         load_dw_params(ch_begin, wv, ws4);
         fold_b(bf, braw, s_);
         if constexpr (BF16) pack_planes(bf, b16);
-        if (wrow < WROWS) Wl[ch_begin & 1][wrow][q] = fold_dw(wv, ws4);
+        if (wrow < WROWS) Wl[ch_begin & 1][wrow][q] = fold_dw(ch_begin, wv, ws4);
     }
     // The A fragments take their final form once, here (after the first chunk's parameter loads have been issued): the
     // stem's border taps become zeros, and for the bf16 products the pixels are packed (and split) so that the chunk loop
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALLC ? 4 : 
                     bi = biall[c - 1];
                 }
         } else {
-            if (wrow < WROWS) Wl[(ch + 1) & 1][wrow][q] = fold_dw(wln, wsn);
+            if (wrow < WROWS) Wl[(ch + 1) & 1][wrow][q] = fold_dw(chn, wln, wsn);
             // the next chunk's B fragments take their place now, not at the end of the chunk: a wait for their loads there
             // would also wait for the depthwise phase's stores, which have only just been issued
             fold_b(bf, bfn, scn);

@@ -611,15 +611,24 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
             if (step == NOUT) {
                 const int cb = chunk * XCH + q * 4;
                 const bool st_ok = tvalid && img_ok && cb < Cexp;
-                float* dst = y + (((size_t)(img_ok ? img0 : 0) * (HO * HO) + trow * HO) * Cexp + (cb < Cexp ? cb : 0));
+                const size_t dst_off = ((size_t)(img_ok ? img0 : 0) * (HO * HO) + trow * HO) * Cexp + (cb < Cexp ? cb : 0);
+                float* dst = y + dst_off;
                 if (st_ok) {
                     if constexpr (STRIDE == 2) {   // 7 x 7 output: cache resident, plain stores
 #pragma unroll
                         for (int l2 = 0; l2 < NOUT; ++l2)
                             if (2 * cg + l2 < HO) *reinterpret_cast<float4*>(dst + (size_t)(2 * cg + l2) * Cexp) = o[l2];
                     } else {
+                        // a running pointer (one step per output, backwards for the mirrored half): seven precomputed 64-bit
+                        // pixel offsets would be spilled, and a spill reload between two stores waits for the first store
+                        size_t off = dst_off + (th ? (size_t)(HW - 1) * Cexp : (size_t)0);
+                        const long long step = th ? -(long long)Cexp : (long long)Cexp;
 #pragma unroll
-                        for (int l2 = 0; l2 < HALF; ++l2) x3_stream_store(dst + (size_t)ecol(l2) * Cexp, o[l2]);
+                        for (int l2 = 0; l2 < HALF; ++l2) {
+                            x3_stream_store(y + off, o[l2]);
+                            off += step;
+                            asm volatile("" : "+v"(off));      // keep it a running offset
+                        }
                     }
                 }
                 if (tvalid) *reinterpret_cast<float4*>(&red[task][q * 4]) = ps;

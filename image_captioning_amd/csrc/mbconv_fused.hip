@@ -37,7 +37,9 @@ __device__ __forceinline__ xd_f32x2 xd_swish2(xd_f32x2 v) {
     return v * t;
 }
 
-// Workgroups whose LDS footprint fits a CU three times are compiled for three waves per SIMD, the others for two.
+// Workgroups whose LDS footprint fits a CU three times are compiled for three waves per SIMD, the others for two (and so is the
+// 40-channel stride-2 layer on split products: at three it spills, and a spill reload between two output stores, or before a
+// barrier, waits for the stores themselves - measured 2 % slower than two waves without spills).
 template <int KS, int S, int TH, int TW, bool WIDE = false>
 constexpr int xd_waves() {
     if (WIDE) return 2;   // the stem's bf16 variant holds the fp32 patch and its packed copy at once: 256-register budget
@@ -56,7 +58,7 @@ constexpr int xd_waves() {
 // wait for the previous chunk's output stores (vmcnt counts loads and stores in one order).  Only where registers and LDS
 // allow it without losing a workgroup per CU: the 16-channel layer (three chunks).
 template <int CIN, int KS, int S, int TH, int TW, int SW, bool STEM = false, int PROD = 0, int ALLC = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALLC ? 4 : xd_waves<KS, S, TH, TW, STEM && PROD == 1>()))) void expand_dw_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALLC ? 4 : (PROD == 3 && S == 2 && CIN == 40) ? 2 : xd_waves<KS, S, TH, TW, STEM && PROD == 1>()))) void expand_dw_kernel(
     const float* __restrict__ x, const float* __restrict__ we, const float* __restrict__ es, const float* __restrict__ eb,
     const float* __restrict__ wd, const float* __restrict__ dsc, const float* __restrict__ dbi, float* __restrict__ y,
     float* __restrict__ partial, int H, int W, int Cexp, int pad_t, int pad_l, int Ho, int Wo, int tiles_w, int cpg,

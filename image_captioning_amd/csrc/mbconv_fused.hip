@@ -23,6 +23,7 @@ typedef __bf16 xd_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 xd_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
 typedef float xd_f32x4 __attribute__((ext_vector_type(4)));
+typedef short xd_s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XD_CC = 32;            // expanded channels per chunk (one MFMA column block)
 constexpr int XD_LDE = XD_CC + 4;    // padded row of E (16-byte aligned rows, consecutive pixels start 4 banks apart)
@@ -298,15 +299,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALLC ? 4 : 
                     if constexpr (BF16) {
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) {
+                            // the last chunk of a lane half that holds 4 (not 8) values is a K = 8 block: the halves of its
+                            // packed words that would only carry zeros are never read, so they cost no registers
+                            auto mm = [&](const uint4& a, const uint4& b) {
+                                if constexpr (KH2 % 8 == 4) {
+                                    if (c == NCH - 1) {
+                                        acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(xd_s16x4, make_uint2(a.x, a.y)),
+                                                                                       __builtin_bit_cast(xd_s16x4, make_uint2(b.x, b.y)), acc, 0, 0, 0);
+                                        return;
+                                    }
+                                }
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xd_bf16x8, a), __builtin_bit_cast(xd_bf16x8, b), acc, 0, 0, 0);
+                            };
                             if constexpr (NPL == 3) {   // smallest terms first: (a plane, b plane) with plane sum <= 2
                                 constexpr int pa[5] = {2, 0, 1, 1, 0}, pb[5] = {0, 2, 1, 0, 1};
 #pragma unroll
-                                for (int t5 = 0; t5 < 5; ++t5)
-                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xd_bf16x8, a16[i][pa[t5]][c]),
-                                                                                  __builtin_bit_cast(xd_bf16x8, b16[pb[t5]][c]), acc, 0, 0, 0);
+                                for (int t5 = 0; t5 < 5; ++t5) mm(a16[i][pa[t5]][c], b16[pb[t5]][c]);
                             }
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xd_bf16x8, a16[i][0][c]),
-                                                                          __builtin_bit_cast(xd_bf16x8, b16[0][c]), acc, 0, 0, 0);
+                            mm(a16[i][0][c], b16[0][c]);
                         }
                     } else {
 #pragma unroll

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
     constexpr int NOUT = STRIDE == 2 ? 2 : HALF;                                            // outputs per task
     constexpr int NIN = STRIDE == 2 ? (NOUT - 1) * 2 + KS : HALF + PAD;                     // input columns per task
     static_assert(STRIDE == 1 || STRIDE == 2, "stride");
-    constexpr int PD = 2;                                   // LDS reads of E in flight ahead of their use
+    constexpr int PD = (CIN == 112 && KS == 5 && STRIDE == 1) ? 1 : 2;   // LDS reads of E in flight ahead of their use (one where two would spill)
     constexpr int NKL = NK > NKR ? NK - NKR : 0;            // K slices whose A planes live in LDS
     constexpr int WROWS = KS * KS + 2;
     static_assert(WROWS * NQ <= 512, "one float4 parameter entry per thread");

@@ -561,7 +561,10 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
             return *reinterpret_cast<const float4*>(erow + ecol(u) * ES);
         }
     };
-    auto dw_step = [&](int item, int step, int buf, int chunk) {
+    // guarded = false: the caller knows that every working lane stores (steady-state chunks of the stride-1 form are whole, the
+    // image exists, wave 7 is not here) - the stores then sit in straight-line code, the compiler can count them, and a later
+    // wait for a load issued before them need not wait for them
+    auto dw_step = [&](int item, int step, int buf, int chunk, bool guarded = true) {
         if (item < KS) {
             const int dr = item;
             const float* erow = &E[((STRIDE * trow + dr + PAD - PT) * HW) * ES + q * 4];
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
             asm volatile("" : "+v"(o[l].x), "+v"(o[l].y), "+v"(o[l].z), "+v"(o[l].w), "+v"(ps.x), "+v"(ps.y), "+v"(ps.z), "+v"(ps.w));
             if (step == NOUT) {
                 const int cb = chunk * XCH + q * 4;
-                const bool st_ok = tvalid && img_ok && cb < Cexp;
+                const bool st_ok = !guarded || (tvalid && img_ok && cb < Cexp);
                 const size_t dst_off = ((size_t)(img_ok ? img0 : 0) * (HO * HO) + trow * HO) * Cexp + (cb < Cexp ? cb : 0);
                 float* dst = y + dst_off;
                 if (st_ok) {
@@ -703,6 +706,14 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
                 else load_b(min(c + 2, c1 - 1), 0, bnxt);
                 load_a((t + 1) % NK, anxt);
                 constexpr int k0 = (t * NITEMS + NK - 1) / NK, k1 = ((t + 1) * NITEMS + NK - 1) / NK;
+                if constexpr (t == NK - 1) {
+                    // the next chunk's parameters (requested at the top of this chunk) take their place before the last slice,
+                    // i.e. before this chunk's output stores are issued: behind the stores the wait for these loads would be a
+                    // wait for the stores as well.  wds[buf ^ 1] is free: its readers were the previous chunk's steps.
+                    store_dw_params(buf ^ 1);
+#pragma unroll
+                    for (int j = 0; j < NCB; ++j) asm volatile("" : "+v"(esc[j]), "+v"(ebc[j]));
+                }
                 // steps of the items [k0, k1) that run beside this slice, in order: (item, step) pairs numbered g = 0 .. S - 1
                 constexpr int S = (k1 > k0 ? (k1 - k0 - (k1 == NITEMS ? 1 : 0)) * ROW_STEPS + (k1 == NITEMS ? EPI_STEPS : 0) : 0);
                 x3_static_for<NM>([&](auto mc) {
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
                             constexpr int g = decltype(gc)::value;
                             if constexpr (g * NM / S == m) {
                                 constexpr int item = k0 + g / ROW_STEPS;        // only the chunk's last item is shorter
-                                dw_step(item, g - (item - k0) * ROW_STEPS, buf, c);
+                                dw_step(item, g - (item - k0) * ROW_STEPS, buf, c, STRIDE != 1);
                             }
                         });
                     }
@@ -730,7 +741,6 @@ __global__ __launch_bounds__(512, 1) void expand_dw_img14_w8_kernel(const float*
         x3_lds_barrier();
         X3_T(4);             // barrier after the slices
         pooled_reduce(c);
-        store_dw_params(buf ^ 1);
         e_write();
         X3_T(5);             // pooled + E write
         x3_lds_barrier();

@@ -190,14 +190,17 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
     float4 rg16[(A16 && GATE) ? AP16 : 1][2];
     unsigned okmask_s[NSET];
     // every load is unconditional (clamped address); out-of-range elements are zeroed when the slice goes to LDS
-    auto gload = [&](int t, auto set_tag) {
+    // FAST (a whole slice inside the contraction, linear form): nothing is masked.  Rows beyond M or N read row 0 (the
+    // clamped pointers above) instead of zeros; their products land in output rows / columns that the epilogue never stores.
+    auto gload = [&](int t, auto set_tag, auto fast_tag) {
         constexpr int S = decltype(set_tag)::value;
+        constexpr bool FAST = decltype(fast_tag)::value;
         unsigned okmask = 0;
         const int ka = t * BK + a_k4, kb = t * BK + b_k8;
         if constexpr (A16) {
 #pragma unroll
             for (int i = 0; i < AP16; ++i) {
-                bool ok = a16_ok[i] && kb < klen;
+                bool ok = FAST || (a16_ok[i] && kb < klen);
                 const unsigned short* src = a16_src[i] + kb;
                 if constexpr (CONV == 1) {
                     const int ih = a16_ih[i] + c_kh, iw = a16_iw[i] + c_kw;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
                 ra[S][i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ((size_t)ih * p.W + iw) * 4 : p.x);
                 okmask |= ok ? (1u << i) : 0u;
             } else {
-                const bool ok = a_ok[i] && ka < klen;
+                const bool ok = FAST || (a_ok[i] && ka < klen);
                 ra[S][i] = *reinterpret_cast<const float4*>(ok ? a_src[i] + ka : p.x);
                 if (GATE) rg[S][i] = *reinterpret_cast<const float4*>(ok ? g_src[i] + ka : p.gate);
                 okmask |= ok ? (1u << i) : 0u;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            const bool ok = b_ok[i] && kb < klen;
+            const bool ok = FAST || (b_ok[i] && kb < klen);
 #pragma unroll
             for (int sp = 0; sp < SPLIT; ++sp)
                 rb[S][sp][i] = *reinterpret_cast<const uint4*>(ok ? b_src[i] + (size_t)sp * p.N * p.K + kb : p.w);
@@ -251,9 +254,9 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
         }
         okmask_s[S] = okmask;
     };
-    auto lds_store = [&](int buf, auto set_tag) {
+    auto lds_store = [&](int buf, auto set_tag, auto fast_tag) {
         constexpr int S = decltype(set_tag)::value;
-        const unsigned okmask = okmask_s[S];
+        const unsigned okmask = decltype(fast_tag)::value ? 0xffffffffu : okmask_s[S];
         if constexpr (A16) {
 #pragma unroll
             for (int i = 0; i < AP16; ++i) {
@@ -353,30 +356,37 @@ __global__ __launch_bounds__(256, SPLIT == 3 ? 2 : 1) void gemm_bf16_kernel(cons
 
     const int nk = (klen + BK - 1) / BK;
     using T0 = std::integral_constant<int, 0>;
-    gload(0, T0{});
-    lds_store(0, T0{});
+    using Slow = std::false_type;
     if constexpr (NBUF == 1) {
         // one LDS buffer: [wait for slice t's registers, split, store] [barrier] [fetch slice t+1] [MFMAs] [barrier]; the
         // CU's other workgroup fills the gaps
-        for (int t = 0; t < nk; ++t) {
-            if (t > 0) lds_store(0, T0{});
-            __syncthreads();
-            if (t + 1 < nk) gload(t + 1, T0{});
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(2);      // the matrix-core phase outranks the other workgroup's staging arithmetic
-            compute(0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-        }
+        auto k_loop = [&](auto fast_tag) {
+            gload(0, T0{}, fast_tag);
+            for (int t = 0; t < nk; ++t) {
+                lds_store(0, T0{}, fast_tag);
+                __syncthreads();
+                if (t + 1 < nk) gload(t + 1, T0{}, fast_tag);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(2);      // the matrix-core phase outranks the other workgroup's staging arithmetic
+                compute(0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+            }
+        };
+        // the column statistics count every row of the tile, so that form keeps the zeroed rows
+        if (!STATS && CONV == 0 && klen % BK == 0) k_loop(std::true_type{});
+        else k_loop(Slow{});
     } else {
+        gload(0, T0{}, Slow{});
+        lds_store(0, T0{}, Slow{});
         __syncthreads();
         int cur = 0;
         for (int t = 0; t < nk; ++t) {
             const bool more = t + 1 < nk;
-            if (more) gload(t + 1, T0{});
+            if (more) gload(t + 1, T0{}, Slow{});
             compute(cur);
-            if (more) lds_store(cur ^ 1, T0{});
+            if (more) lds_store(cur ^ 1, T0{}, Slow{});
             __syncthreads();
             cur ^= 1;
         }

@@ -505,7 +505,7 @@ def decode_b1(torch, dev):
 
 CAPTION_DTYPES = {"f32": "f32", "f32x3": "f32x3"}
 DTYPE_NOTES = {"f32": "every product on the fp32 matrix-core instruction, fp32 tensors",
-               "f32x3": "fp32-accurate, not the plain-fp32 instruction path of rounds 1-2's `f32` lines: the MFMA-bound GEMMs (1x1 convolutions "
+               "f32x3": "fp32-accurate, not the plain-fp32 instruction path of the `f32` lines (`plain_f32`): the MFMA-bound GEMMs (1x1 convolutions "
                         "with a long contraction, the fused MBConv expand GEMMs, the decoder's fc1 / vocabulary projection) as six exact bf16 "
                         "products per multiply from three-way operand splits on the bf16 matrix cores, fp32 accumulate; every other kernel plain "
                         "fp32; fp32 tensors; the plain-fp32 figure of the same step is in `plain_f32`",
@@ -862,7 +862,7 @@ def main():
                "unit": "captions/s", "ms_per_step": alt_elapsed / args.steps * 1e3,
                "tolerance": "features 1e-2, logits 2e-2 of their largest magnitude vs the f32 path (tests/test_gpu_bf16.py)"}
 
-    # the same step on the plain fp32 matrix-core instruction (the `f32` path of earlier rounds' lines), same K steps and barriers
+    # the same step on the plain fp32 matrix-core instruction (the `f32` path), same K steps and barriers
     plain = None
     if not train and args.dtype == "f32x3" and not args.no_plain_f32:
         ops.set_compute_dtype("f32")
